@@ -1,0 +1,221 @@
+"""Generate tests/golden/*.npz by running the IMPORTED reference (fp32, CPU) on seeded inputs.
+
+Run only in the build container:  python -m oracle.make_golden
+Weights are not stored: every fixture records (model kind, dims, weight seed) and the tests
+regenerate identical weights with esm_amd.synth.  Stored: inputs + reference outputs (fp32,
+sub-sampled where large).  A fixture is data only - no reference source travels.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from esm_amd import synth  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: (np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def esmc_case(name, d, H, NL, lengths, wseed, tseed, sequence_id=None, pad_to=None, store_hidden=(0, -1),
+              token_stride=1):
+    w = synth.esmc_weights(d, NL, seed=wseed)
+    m = ref_import.build_esmc(d, H, NL, w)
+    tok = synth.synth_tokens(lengths, pad_to=pad_to, seed=tseed)
+    with torch.no_grad():
+        out = m(tok, sequence_id=sequence_id)
+    arrays = dict(
+        kind="esmc", d=d, H=H, NL=NL, wseed=wseed, tokens=_np(tok), token_stride=token_stride,
+        sequence_logits=_np(out.sequence_logits[:, ::token_stride]),
+        embeddings=_np(out.embeddings[:, ::token_stride]),
+        hidden_layers=np.asarray([i % NL for i in store_hidden]),
+        hidden_states=_np(out.hidden_states[[i % NL for i in store_hidden]][:, :, ::token_stride]),
+    )
+    if sequence_id is not None:
+        arrays["sequence_id"] = _np(sequence_id)
+    save(name, **arrays)
+
+
+def packed_row(lengths, total):
+    """One bin-packed row: tokens of several sequences back-to-back + int64 sequence_id."""
+    toks = [synth.synth_tokens([n], seed=900 + i)[0] for i, n in enumerate(lengths)]
+    row = torch.full((total,), 1, dtype=torch.int64)
+    sid = torch.full((total,), len(lengths), dtype=torch.int64)  # trailing pads form their own id
+    pos = 0
+    for i, t in enumerate(toks):
+        row[pos: pos + len(t)] = t
+        sid[pos: pos + len(t)] = i
+        pos += len(t)
+    return row, sid
+
+
+def stack_case(name, d, H, NL, L, wseed):
+    """True-width trunk, few layers: input activations -> (post, pre)."""
+    w = synth.make_weights(synth.trunk_shapes("", d, NL), seed=wseed)
+    m = ref_import.build_stack(d, H, NL, w)
+    g = torch.Generator().manual_seed(wseed + 17)
+    x = torch.randn(2, L, d, generator=g)
+    sid = torch.ones(2, L, dtype=torch.bool)
+    sid[1, L - 9:] = False
+    with torch.no_grad():
+        post, pre, hid = m(x, sequence_id=sid)
+    save(name, kind="stack", d=d, H=H, NL=NL, wseed=wseed, x=_np(x), sequence_id=_np(sid),
+         post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4)
+
+
+def esm3_inputs(B, L, lengths, seed, with_tracks=True):
+    g = torch.Generator().manual_seed(seed)
+    seq = synth.synth_tokens(lengths, pad_to=L, seed=seed)
+    kw = dict(sequence_tokens=seq)
+    kw["structure_tokens"] = torch.randint(0, 4096, (B, L), generator=g)
+    coords = synth.synth_backbone(B, L, seed=seed + 1, nan_frac=0.15)
+    for b, n in enumerate(lengths):
+        coords[b, n - 1] = float("inf")  # EOS row
+        coords[b, n:] = float("nan")  # pad rows
+    kw["structure_coords"] = coords
+    if with_tracks:
+        kw["ss8_tokens"] = torch.randint(0, 11, (B, L), generator=g)
+        kw["sasa_tokens"] = torch.randint(0, 19, (B, L), generator=g)
+        f = torch.randint(0, 260, (B, L, 8), generator=g)
+        f[:, : L // 3] = 0
+        kw["function_tokens"] = f
+        r = torch.randint(0, 1478, (B, L, 16), generator=g)
+        r[:, :, 3:] = 0
+        r[:, ::2] = 0
+        kw["residue_annotation_tokens"] = r
+        kw["average_plddt"] = torch.rand(B, L, generator=g)
+        kw["per_res_plddt"] = torch.rand(B, L, generator=g)
+    return kw
+
+
+def esm3_case(name, d, H, VH, NL, B, L, lengths, wseed, iseed, extra=None, with_tracks=True, big_stride=1):
+    w = synth.esm3_weights(d, NL, VH, seed=wseed)
+    m = ref_import.build_esm3(d, H, VH, NL, w)
+    kw = esm3_inputs(B, L, lengths, iseed, with_tracks)
+    if extra:
+        kw.update(extra)
+    with torch.no_grad():
+        out = m(**kw)
+    arrays = dict(kind="esm3", d=d, H=H, VH=VH, NL=NL, wseed=wseed, big_stride=big_stride)
+    for k, v in kw.items():
+        arrays["in_" + k] = _np(v)
+    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits", "embeddings"):
+        arrays[k] = _np(getattr(out, k))
+    for k in ("structure_logits", "function_logits", "residue_logits"):
+        arrays[k] = _np(getattr(out, k)[:, ::big_stride])
+    save(name, **arrays)
+
+
+def geom_case(name, d, VH, B, L, wseed, variant):
+    """GeometricReasoningOriginalImpl alone (block 0 of a 1-layer geom stack shares the weights)."""
+    ref_import.install()
+    from esm.layers.geom_attention import GeometricReasoningOriginalImpl
+    from esm.utils.structure.affine3d import build_affine3d_from_coordinates
+
+    shapes = {k[len("blocks.0.geom_attn."):]: v for k, v in
+              synth.trunk_shapes("", d, 1, v_heads=VH, n_layers_geom=1).items() if "geom_attn" in k}
+    w = synth.make_weights({"blocks.0.geom_attn." + k: v for k, v in shapes.items()}, seed=wseed)
+    mod = GeometricReasoningOriginalImpl(c_s=d, v_heads=VH, mask_and_zero_frameless=True).eval()
+    mod.load_state_dict({k[len("blocks.0.geom_attn."):]: v for k, v in w.items()}, strict=True)
+    g = torch.Generator().manual_seed(wseed + 3)
+    s = torch.randn(B, L, d, generator=g)
+    coords = synth.synth_backbone(B, L, seed=wseed + 4, nan_frac=0.2)
+    sid = None
+    chain = torch.zeros(B, L, dtype=torch.int64)
+    if variant == "nostruct":
+        coords[:] = float("nan")
+    elif variant == "multichain":
+        chain[:, L // 2:] = 1
+    elif variant == "binpacked":
+        sid = torch.zeros(B, L, dtype=torch.int64)
+        sid[:, L // 3:] = 1
+        sid[:, 2 * L // 3:] = 2
+    elif variant == "onerow_frameless":
+        coords[0] = float("nan")
+    affine, mask = build_affine3d_from_coordinates(coords)
+    with torch.no_grad():
+        out = mod(s, affine, mask, sid, chain)
+    arrays = dict(kind="geom", d=d, VH=VH, wseed=wseed, s=_np(s), coords=_np(coords), chain_id=_np(chain),
+                  out=_np(out), affine=_np(affine.tensor), affine_mask=_np(mask))
+    if sid is not None:
+        arrays["sequence_id"] = _np(sid)
+    save(name, **arrays)
+
+
+def frames_case(name):
+    B, L = 3, 40
+    coords = synth.synth_backbone(B, L, seed=77, nan_frac=0.25)
+    coords[1] = float("nan")  # a batch row with no coordinates at all -> identity rotation
+    coords[2, 5, 1, 0] = 2e6  # beyond _MAX_SUPPORTED_DISTANCE -> frameless
+    affine, mask = ref_import.build_frames(coords)
+    save(name, kind="frames", coords=_np(coords), affine=_np(affine.tensor), mask=_np(mask))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    # (i) tiny ESMC under the three sequence_id dialects
+    esmc_case("esmc_tiny_bool", 128, 2, 3, [33, 48, 17, 40], wseed=11, tseed=100)
+    row0, sid0 = packed_row([20, 31, 9], 64)
+    row1, sid1 = packed_row([40, 24], 64)
+    tokens = torch.stack([row0, row1])
+    w = synth.esmc_weights(128, 3, seed=11)
+    m = ref_import.build_esmc(128, 2, 3, w)
+    with torch.no_grad():
+        out = m(tokens, sequence_id=torch.stack([sid0, sid1]))
+    save("esmc_tiny_binpacked", kind="esmc", d=128, H=2, NL=3, wseed=11, tokens=_np(tokens), token_stride=1,
+         sequence_id=_np(torch.stack([sid0, sid1])), sequence_logits=_np(out.sequence_logits),
+         embeddings=_np(out.embeddings), hidden_layers=np.asarray([0, 2]),
+         hidden_states=_np(out.hidden_states[[0, 2]]))
+    # no-mask dialect: the stack with sequence_id=None (ESM3.logits / function decoder use this)
+    wst = synth.make_weights(synth.trunk_shapes("", 128, 3), seed=12)
+    st = ref_import.build_stack(128, 2, 3, wst)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 37, 128, generator=g)
+    with torch.no_grad():
+        post, pre, _ = st(x, sequence_id=None)
+    save("stack_tiny_nomask", kind="stack", d=128, H=2, NL=3, wseed=12, x=_np(x), post=_np(post), pre=_np(pre),
+         token_stride=1)
+    # (ii) true-width trunks, 2 layers, L=64
+    for d, H in ((960, 15), (1152, 18), (1536, 24), (2560, 40)):
+        stack_case(f"stack_d{d}", d, H, 2, 64, wseed=20 + H)
+    # (iii) full-depth ESMC-300M-shaped (C1 geometry), 2 x 128
+    esmc_case("esmc_300m_2x128", 960, 15, 30, [128, 101], wseed=31, tseed=300, store_hidden=(0, 14, 29),
+              token_stride=2)
+    # (iv) geometric attention variants
+    for v in ("plain", "nostruct", "multichain", "binpacked", "onerow_frameless"):
+        geom_case(f"geom_{v}", 128, 8, 2, 48, wseed=41, variant=v)
+    geom_case("geom_d1536_vh256", 1536, 256, 1, 40, wseed=43, variant="multichain")
+    # (v) frames
+    frames_case("frames")
+    # (vi) ESM3 end to end, 2 layers
+    esm3_case("esm3_tiny_alltracks", 128, 2, 8, 2, 2, 40, [40, 29], wseed=51, iseed=500)
+    esm3_case("esm3_tiny_seqstruct", 128, 2, 8, 2, 1, 33, [33], wseed=51, iseed=501, with_tracks=False)
+    chain = torch.zeros(2, 40, dtype=torch.int64)
+    chain[0, 22:] = 1
+    sid = torch.zeros(2, 40, dtype=torch.int64)
+    sid[1, 15:] = 1
+    esm3_case("esm3_tiny_chain_seqid", 128, 2, 8, 2, 2, 40, [40, 40], wseed=52, iseed=502,
+              extra=dict(chain_id=chain, sequence_id=sid))
+    esm3_case("esm3_d1536_2layer", 1536, 24, 256, 2, 1, 64, [64], wseed=53, iseed=503, with_tracks=False,
+              big_stride=8)
+
+
+if __name__ == "__main__":
+    main()

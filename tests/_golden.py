@@ -1,0 +1,47 @@
+"""Shared helpers: load a golden fixture, rebuild its weights, run the oracle on its inputs."""
+import os
+
+import numpy as np
+import torch
+
+from esm_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def esm3_kwargs(fx):
+    return {k[3:]: t(v) for k, v in fx.items() if k.startswith("in_")}
+
+
+def weights_for(fx):
+    kind = str(fx["kind"])
+    d, ws = int(fx["d"]), int(fx["wseed"])
+    if kind == "esmc":
+        return synth.esmc_weights(d, int(fx["NL"]), seed=ws)
+    if kind == "stack":
+        return synth.make_weights(synth.trunk_shapes("", d, int(fx["NL"])), seed=ws)
+    if kind == "esm3":
+        return synth.esm3_weights(d, int(fx["NL"]), int(fx["VH"]), seed=ws)
+    if kind == "geom":
+        shapes = {k: v for k, v in synth.trunk_shapes("", d, 1, v_heads=int(fx["VH"]), n_layers_geom=1).items()
+                  if "geom_attn" in k}
+        return synth.make_weights(shapes, seed=ws)
+    raise ValueError(kind)
+
+
+def cosine_min(a, b):
+    """Minimum per-row cosine similarity over the last dim."""
+    a = a.double().reshape(-1, a.shape[-1])
+    b = b.double().reshape(-1, b.shape[-1])
+    num = (a * b).sum(-1)
+    den = a.norm(dim=-1) * b.norm(dim=-1)
+    return float((num / den.clamp_min(1e-30)).min())

@@ -1,0 +1,78 @@
+"""The CPU oracle (oracle/trunk_ref.py) against fixtures produced by the imported reference."""
+import pytest
+import torch
+
+from oracle import trunk_ref
+from tests import _golden as G
+
+TOL = 2e-5  # fp32 vs fp32, different op order
+
+
+def _close(a, b, tol=TOL):
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128"])
+def test_esmc(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    tok = G.t(fx["tokens"])
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
+    out = trunk_ref.esmc_forward(tok, w, int(fx["H"]), int(fx["NL"]), sequence_id=sid)
+    s = int(fx["token_stride"])
+    valid = (tok != 1)[:, ::s]
+    _close(out["sequence_logits"][:, ::s][valid], G.t(fx["sequence_logits"])[valid])
+    _close(out["embeddings"][:, ::s][valid], G.t(fx["embeddings"])[valid])
+    hl = [int(i) for i in fx["hidden_layers"]]
+    _close(out["hidden_states"][hl][:, :, ::s][:, valid], G.t(fx["hidden_states"])[:, valid])
+
+
+@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560"])
+def test_stack(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
+    post, pre, _ = trunk_ref.transformer_stack(G.t(fx["x"]), sid, w, "", int(fx["H"]), int(fx["NL"]))
+    s = int(fx["token_stride"])
+    valid = sid[:, ::s] if sid is not None else torch.ones(post[:, ::s].shape[:2], dtype=torch.bool)
+    _close(post[:, ::s][valid], G.t(fx["post"])[valid])
+    _close(pre[:, ::s][valid], G.t(fx["pre"])[valid])
+
+
+def test_frames():
+    fx = G.load("frames")
+    rot, trans, mask = trunk_ref.build_frames(G.t(fx["coords"]))
+    aff = G.t(fx["affine"])
+    assert torch.equal(mask, G.t(fx["mask"]))
+    _close(rot.flatten(-2), aff[..., :9], 1e-6)
+    _close(trans, aff[..., 9:], 1e-6)
+
+
+@pytest.mark.parametrize("name", ["geom_plain", "geom_nostruct", "geom_multichain", "geom_binpacked",
+                                  "geom_onerow_frameless", "geom_d1536_vh256"])
+def test_geom(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    rot, trans, mask = trunk_ref.build_frames(G.t(fx["coords"]))
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
+    out = trunk_ref.geometric_attention(G.t(fx["s"]), rot, trans, mask, sid, G.t(fx["chain_id"]), w,
+                                        "blocks.0.geom_attn.", int(fx["VH"]))
+    _close(out, G.t(fx["out"]))
+    if name == "geom_nostruct":
+        assert out.abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name", ["esm3_tiny_alltracks", "esm3_tiny_seqstruct", "esm3_tiny_chain_seqid",
+                                  "esm3_d1536_2layer"])
+def test_esm3(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    out = trunk_ref.esm3_forward(w, int(fx["H"]), int(fx["VH"]), int(fx["NL"]), **G.esm3_kwargs(fx))
+    bs = int(fx["big_stride"])
+    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits", "embeddings"):
+        _close(out[k], G.t(fx[k]))
+    for k in ("structure_logits", "function_logits", "residue_logits"):
+        _close(out[k][:, ::bs], G.t(fx[k]))
