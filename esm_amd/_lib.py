@@ -1,0 +1,103 @@
+"""ctypes binding of libesmk.so (the C-ABI declared in include/esmk.h).
+
+The product path has NO fallback: if the HIP library is missing or a call fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libesmk.so")
+
+F32, BF16 = 0, 1
+PACK_PLAIN, PACK_SWIGLU = 0, 1
+EPI_BF16, EPI_F32, EPI_SWIGLU, EPI_RESIDUAL, EPI_BIAS_GELU = 0, 1, 2, 3, 4
+ATTN_QBLK = 128
+
+vp = C.c_void_p
+
+
+class EsmkEsm3Encoder(C.Structure):
+    _fields_ = [(n, vp) for n in ("sequence_embed", "plddt_w", "plddt_b", "res_plddt_w", "res_plddt_b",
+                                  "structure_embed", "ss8_embed", "sasa_embed", "function_embed", "residue_embed")]
+
+
+class EsmkLayer(C.Structure):
+    _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "w_qkv", "qln_g", "kln_g", "w_o", "ln2_g", "ln2_b", "w_ffn1",
+                                  "w_ffn2", "geom_ln_g", "w_geom_proj", "w_geom_out", "geom_dist_scale",
+                                  "geom_rot_scale")]
+
+
+class EsmkTrunk(C.Structure):
+    _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("n_layers", C.c_int), ("ffn_hidden", C.c_int),
+                ("v_heads", C.c_int), ("residual_scale", C.c_float), ("layers", C.POINTER(EsmkLayer)),
+                ("final_norm_g", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int)]
+
+
+class EsmkBatch(C.Structure):
+    _fields_ = [("n_tokens", C.c_int), ("n_segments", C.c_int), ("cu_seqlens", vp), ("positions", vp),
+                ("qblk_map", vp), ("n_qblk", C.c_int), ("affine", vp), ("affine_mask", vp), ("seq_id", vp),
+                ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int)]
+
+
+class EsmkHead(C.Structure):
+    _fields_ = [("w0", vp), ("b0", vp), ("ln_g", vp), ("ln_b", vp), ("w3", vp), ("b3", vp), ("out_dim", C.c_int)]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_cabi_symbols.py checks against esmk.h
+SIGNATURES = {
+    "esmk_version": (C.c_int, []),
+    "esmk_last_error": (C.c_char_p, []),
+    "esmk_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "esmk_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "esmk_layernorm": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "esmk_gemm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
+    "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+    "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),
+    "esmk_attn_varlen": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "esmk_embed": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "esmk_esm3_encode": (C.c_int, [C.POINTER(EsmkEsm3Encoder), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
+    "esmk_frames": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
+    "esmk_geom_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "esmk_geom_attn": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "esmk_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(EsmkTrunk), C.c_int]),
+    "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
+    "esmk_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
+    "esmk_head_forward": (C.c_int, [C.POINTER(EsmkHead), vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+}
+
+
+class EsmkError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libesmk.so; raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EsmkError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(or `make -C esm_amd/csrc`). There is no non-HIP fallback.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc < 0:
+        msg = lib().esmk_last_error().decode(errors="replace")
+        raise EsmkError(f"{what or 'esmk'} failed (code {rc}): {msg}")
+    return rc
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor / None."""
+    return None if t is None else t.data_ptr()

@@ -1,0 +1,97 @@
+"""Minimal re-declaration of the reference's I/O types for the trunk path
+(reference esm/sdk/api.py:201-282,368-411; esm/utils/sampling.py:42-106).  Field names and meanings
+are the reference's; everything unrelated to the trunk forward (Forge clients, ESMProtein string/PDB
+handling, generation configs) is out of scope.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, fields
+
+import torch
+
+
+@dataclass
+class ESMProteinTensor:
+    sequence: torch.Tensor | None = None
+    structure: torch.Tensor | None = None
+    secondary_structure: torch.Tensor | None = None
+    sasa: torch.Tensor | None = None
+    function: torch.Tensor | None = None
+    residue_annotations: torch.Tensor | None = None
+    coordinates: torch.Tensor | None = None
+    potential_sequence_of_concern: bool = False
+
+    def _tensors(self):
+        return {f.name: getattr(self, f.name) for f in fields(ESMProteinTensor)
+                if isinstance(getattr(self, f.name), torch.Tensor)}
+
+    def __len__(self) -> int:
+        lens = {v.size(0) for v in self._tensors().values()}
+        if not lens:
+            return 0
+        if len(lens) != 1:
+            raise ValueError(f"Either no tracks or inconsistent length: {lens}")
+        return next(iter(lens))
+
+    @property
+    def device(self):
+        devs = {v.device for v in self._tensors().values()}
+        assert len(devs) == 1, devs
+        return next(iter(devs))
+
+    def to(self, device_or_dtype):
+        for k, v in self._tensors().items():
+            setattr(self, k, v.to(device_or_dtype))
+        return self
+
+
+class _BatchedESMProteinTensor(ESMProteinTensor):
+    @staticmethod
+    def from_protein_tensor(protein: ESMProteinTensor):
+        u = lambda x: x.unsqueeze(0) if x is not None else None
+        return _BatchedESMProteinTensor(
+            sequence=u(protein.sequence), structure=u(protein.structure),
+            secondary_structure=u(protein.secondary_structure), sasa=u(protein.sasa), function=u(protein.function),
+            residue_annotations=u(protein.residue_annotations), coordinates=u(protein.coordinates))
+
+    def __len__(self) -> int:
+        lens = {v.size(1) for v in self._tensors().values()}
+        return next(iter(lens)) if lens else 0
+
+    @property
+    def batch_size(self) -> int:
+        return next(iter({v.size(0) for v in self._tensors().values()}))
+
+
+@dataclass
+class ForwardTrackData:
+    sequence: torch.Tensor | None = None
+    structure: torch.Tensor | None = None
+    secondary_structure: torch.Tensor | None = None
+    sasa: torch.Tensor | None = None
+    function: torch.Tensor | None = None
+
+
+@dataclass
+class LogitsConfig:
+    sequence: bool = False
+    structure: bool = False
+    secondary_structure: bool = False
+    sasa: bool = False
+    function: bool = False
+    residue_annotations: bool = False
+    return_embeddings: bool = False
+    return_hidden_states: bool = False
+    return_mean_embedding: bool = False
+    return_mean_hidden_states: bool = False
+    ith_hidden_layer: int = -1
+
+
+@dataclass
+class LogitsOutput:
+    logits: ForwardTrackData | None = None
+    embeddings: torch.Tensor | None = None
+    mean_embedding: torch.Tensor | None = None
+    residue_annotation_logits: torch.Tensor | None = None
+    hidden_states: torch.Tensor | None = None
+    mean_hidden_state: torch.Tensor | None = None

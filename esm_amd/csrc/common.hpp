@@ -1,0 +1,60 @@
+// Shared device/host helpers for the gfx950 trunk kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/esmk.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// error plumbing (host)
+void esmk_set_error(const char* fmt, ...);
+#define ESMK_FAIL(code, ...)         \
+    do {                             \
+        esmk_set_error(__VA_ARGS__); \
+        return (code);               \
+    } while (0)
+#define ESMK_CHECK_LAUNCH(name)                                                        \
+    do {                                                                               \
+        hipError_t e__ = hipGetLastError();                                            \
+        if (e__ != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+// ---- bf16 <-> f32 (round-to-nearest-even through the hardware cvt; NaN stays NaN) ----
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
+    return __uint_as_float(((unsigned int)u) << 16);
+}
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+__device__ __forceinline__ unsigned int pack_bf16x2(float lo, float hi) {
+    return (unsigned int)f32_to_bf16_bits(lo) | ((unsigned int)f32_to_bf16_bits(hi) << 16);
+}
+
+// XCD-aware bijective remap of a 1-D block id: blocks that are dispatched round-robin over the 8 XCDs
+// get contiguous chunks of the logical id space, so neighbours in logical order share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, idx = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}

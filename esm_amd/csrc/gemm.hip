@@ -1,0 +1,265 @@
+// bf16 MFMA GEMM with fused epilogues:  out = epi(A[M,K] . W[N,K]^T)
+//
+// Orientation: the MFMA "M" dimension is the OUTPUT CHANNEL (rows of W) and the MFMA "N" dimension is the
+// TOKEN, i.e. each workgroup computes a (channels x tokens) tile of out^T.  With v_mfma_f32_16x16x32_bf16
+// a lane then holds 4 consecutive output channels of ONE token in one accumulator, so every epilogue
+// (bf16 store, SwiGLU gate*up, fp32 residual read-modify-write) works on 8/16-byte row-major pieces.
+//
+// Tile: 128 channels x 128 tokens x BK=64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 MFMA tiles.
+// Both operands are K-contiguous in memory, staged global->LDS with global_load_lds_dwordx4 (no VGPR
+// round trip) into double-buffered 16 KiB tiles; one barrier per K-step.  LDS rows are 128 B; the 16-byte
+// chunk index is XOR-swizzled with (row>>1)&7 - applied on the per-lane SOURCE address (the DMA writes
+// LDS linearly) and on the ds_read_b128 address - which makes the 16-lane ds_read_b128 groups
+// conflict-free.
+#include "common.hpp"
+
+namespace {
+
+constexpr int BW = 128;  // output channels per block
+constexpr int BT = 128;  // tokens per block
+constexpr int BK = 64;
+constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ A, int lda,
+                                                      const __bf16* __restrict__ W, int ldw, int M, int N,
+                                                      int ksteps, const float* __restrict__ bias, float alpha,
+                                                      void* __restrict__ out, int n_ctile, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int ttile = id / n_ctile, ctile = id - ttile * n_ctile;
+    const int c0 = ctile * BW, t0 = ttile * BT;
+
+    // ---- staging addresses: wave w owns pieces 4w..4w+3 (8 rows x 128 B each) of both tiles ----
+    const __bf16* wsrc[4];
+    const __bf16* asrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int p = wave * 4 + i;
+        const int r = p * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
+        wsrc[i] = W + (size_t)(c0 + r) * ldw + lc * 8;
+        int tr = t0 + r;
+        tr = tr < M ? tr : M - 1;
+        asrc[i] = A + (size_t)tr * lda + lc * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * (2 * TILE_BYTES) + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i] + kt * BK), LDS_PTR(base + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0,
+                                             0);
+        }
+    };
+
+    const int wr = wave >> 1, wc = wave & 1;  // wave's 64x64 sub-tile: channels wr*64.., tokens wc*64..
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes) inside a tile for kk = 0; kk = 1 flips chunk bit 2
+    int aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ra = wr * 64 + i * 16 + (lane & 15);
+        const int rb = wc * 64 + i * 16 + (lane & 15);
+        aoff[i] = lds_off(ra, lane >> 4);
+        boff[i] = lds_off(rb, lane >> 4);
+    }
+
+    stage(0, 0);
+    for (int kt = 0; kt < ksteps; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
+        if (kt + 1 < ksteps) stage((kt + 1) & 1, kt + 1);
+        const char* wt = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* at = wt + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *(const bf16x8*)(wt + (aoff[i] ^ (kk << 6)));
+                bfr[i] = *(const bf16x8*)(at + (boff[i] ^ (kk << 6)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: acc[i][j][r] = out^T[channel = c0 + wr*64 + i*16 + (lane>>4)*4 + r][token = ... + (lane&15)] ----
+    const int q4 = (lane >> 4) * 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int t = t0 + wc * 64 + j * 16 + (lane & 15);
+        if (t >= M) continue;
+        if constexpr (EPI == ESMK_EPI_SWIGLU) {
+            const int hw = N >> 1;  // output width
+            __bf16* o = (__bf16*)out + (size_t)t * hw;
+#pragma unroll
+            for (int i = 0; i < 4; i += 2) {
+                const int c = ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4;
+                if (c < hw) {
+                    const f32x4 g = acc[i][j], u = acc[i + 1][j];
+                    u32x2 v;
+                    v.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
+                    v.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
+                    *(u32x2*)(o + c) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c = c0 + wr * 64 + i * 16 + q4;
+                if (c >= N) continue;
+                f32x4 v = acc[i][j];
+                const bool full = ((N & 3) == 0);  // then c+3 < N as well
+                if constexpr (EPI == ESMK_EPI_RESIDUAL) {
+                    float* o = (float*)out + (size_t)t * N + c;
+                    f32x4 x = *(f32x4*)o;
+                    x += v * alpha;
+                    *(f32x4*)o = x;
+                } else if constexpr (EPI == ESMK_EPI_BF16 || EPI == ESMK_EPI_BIAS_GELU) {
+                    __bf16* o = (__bf16*)out + (size_t)t * N + c;
+                    if constexpr (EPI == ESMK_EPI_BIAS_GELU) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r] + (c + r < N ? bias[c + r] : 0.f));
+                    }
+                    if (full) {
+                        u32x2 pk;
+                        pk.x = pack_bf16x2(v[0], v[1]);
+                        pk.y = pack_bf16x2(v[2], v[3]);
+                        *(u32x2*)o = pk;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c + r < N) o[r] = (__bf16)v[r];
+                    }
+                } else {  // ESMK_EPI_F32
+                    float* o = (float*)out + (size_t)t * N + c;
+                    if (bias) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += (c + r < N ? bias[c + r] : 0.f);
+                    }
+                    if (full) {
+                        *(f32x4*)o = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (c + r < N) o[r] = v[r];
+                    }
+                }
+            }
+        }
+    }
+}
+
+// fp32 [N,K] row-major -> bf16 [Npad, Kpad], optional SwiGLU row interleave (groups of 16 gate rows then the
+// 16 matching up rows).  One thread per 8 output elements.
+__global__ void pack_weight_kernel(const float* __restrict__ w, __bf16* __restrict__ out, int N, int K, int Npad,
+                                   int Kpad, int mode) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int kchunks = Kpad >> 3;
+    const size_t total = (size_t)Npad * kchunks;
+    if (idx >= total) return;
+    const int prow = (int)(idx / kchunks);
+    const int k0 = (int)(idx - (size_t)prow * kchunks) * 8;
+    int srow = prow;
+    if (mode == ESMK_PACK_SWIGLU) {
+        const int h = N >> 1;
+        const int g = prow >> 5, j = prow & 31;
+        srow = (j < 16) ? (g * 16 + j) : (h + g * 16 + (j - 16));
+        if (g * 16 + (j & 15) >= h) srow = N;  // beyond -> zero
+    }
+    unsigned int pk[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        float a = 0.f, b = 0.f;
+        if (srow < N) {
+            if (k0 + 2 * e < K) a = w[(size_t)srow * K + k0 + 2 * e];
+            if (k0 + 2 * e + 1 < K) b = w[(size_t)srow * K + k0 + 2 * e + 1];
+        }
+        pk[e] = pack_bf16x2(a, b);
+    }
+    *(u32x4*)(out + (size_t)prow * Kpad + k0) = u32x4{pk[0], pk[1], pk[2], pk[3]};
+}
+
+template <int EPI>
+int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
+                hipStream_t s) {
+    const int Kpad = round_up(K, BK);
+    const int n_ctile = round_up(N, BW) / BW;
+    const int n_ttile = (M + BT - 1) / BT;
+    const int nblk = n_ctile * n_ttile;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * TILE_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(nblk), dim3(256), 4 * TILE_BYTES, s, (const __bf16*)A, lda,
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk);
+    ESMK_CHECK_LAUNCH("esmk_gemm");
+    return ESMK_OK;
+}
+
+}  // namespace
+
+extern "C" size_t esmk_packed_weight_bytes(int N, int K) {
+    if (N <= 0 || K <= 0) return 0;
+    return (size_t)round_up(N, BW) * round_up(K, BK) * 2;
+}
+
+extern "C" int esmk_pack_weight(const float* w, void* packed, int N, int K, int mode, esmk_stream_t stream) {
+    if (!w || !packed || N <= 0 || K <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_pack_weight: null pointer or empty shape");
+    if (mode != ESMK_PACK_PLAIN && mode != ESMK_PACK_SWIGLU) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_pack_weight: bad mode");
+    if (mode == ESMK_PACK_SWIGLU && (N % 32) != 0)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_pack_weight: SwiGLU packing needs N %% 32 == 0 (got %d)", N);
+    const int Npad = round_up(N, BW), Kpad = round_up(K, BK);
+    const size_t total = (size_t)Npad * (Kpad / 8);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
+                       (__bf16*)packed, N, K, Npad, Kpad, mode);
+    ESMK_CHECK_LAUNCH("esmk_pack_weight");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                         float alpha, void* out, esmk_stream_t stream) {
+    if (!A || !W || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: null pointer");
+    if (M < 0 || N <= 0 || K <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    if (M == 0) return ESMK_OK;
+    if (lda < round_up(K, BK) || (lda & 7))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: lda=%d must be >= round_up(K,64)=%d and a multiple of 8", lda,
+                  round_up(K, BK));
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue) {
+        case ESMK_EPI_BF16: return launch_gemm<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s);
+        case ESMK_EPI_F32: return launch_gemm<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s);
+        case ESMK_EPI_SWIGLU:
+            if (N % 32) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm: SwiGLU epilogue needs N %% 32 == 0");
+            return launch_gemm<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s);
+        case ESMK_EPI_RESIDUAL:
+            if (N % 4) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm: residual epilogue needs N %% 4 == 0");
+            return launch_gemm<ESMK_EPI_RESIDUAL>(A, lda, W, M, N, K, bias, alpha, out, s);
+        case ESMK_EPI_BIAS_GELU:
+            if (!bias) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bias+gelu epilogue needs a bias");
+            return launch_gemm<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s);
+        default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
+    }
+}

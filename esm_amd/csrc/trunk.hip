@@ -1,0 +1,184 @@
+// Host-side driver: the whole TransformerStack forward (and the RegressionHead) as one C call that only
+// enqueues kernels on the caller's stream.  No allocation, no synchronisation, no global mutable state
+// besides the thread-local error string.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.hpp"
+
+static thread_local char g_err[512] = "";
+
+int esmk_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
+
+void esmk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int esmk_version(void) { return ESMK_VERSION; }
+extern "C" const char* esmk_last_error(void) { return g_err; }
+
+namespace {
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct TrunkWs {
+    size_t xn, qkv, ctx, hbuf, gproj, gout, gscratch, total;
+};
+
+TrunkWs trunk_layout(const esmk_trunk* t, int M) {
+    TrunkWs w{};
+    const size_t d = t->d_model, h = t->ffn_hidden;
+    size_t off = 0;
+    w.xn = off;   off += align256((size_t)M * d * 2);
+    w.qkv = off;  off += align256((size_t)M * 3 * d * 2);
+    w.ctx = off;  off += align256((size_t)M * d * 2);
+    w.hbuf = off; off += align256((size_t)M * h * 2);
+    bool geom = false;
+    for (int i = 0; i < t->n_layers; ++i) geom = geom || (t->layers[i].geom_ln_g != nullptr);
+    if (geom) {
+        const size_t vh = t->v_heads;
+        w.gproj = off;    off += align256((size_t)M * 15 * vh * 4);
+        w.gout = off;     off += align256((size_t)M * round_up(3 * (int)vh, 64) * 2);
+        w.gscratch = off; off += align256(esmk_geom_scratch_bytes(M, (int)vh));
+    }
+    w.total = off;
+    return w;
+}
+
+int validate_trunk(const esmk_trunk* t) {
+    if (!t || !t->layers || !t->final_norm_g || !t->rope_cos || !t->rope_sin)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk: null descriptor field");
+    if (t->d_model <= 0 || t->n_heads <= 0 || t->d_model != t->n_heads * 64)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_trunk: d_model=%d must be 64*n_heads (n_heads=%d)", t->d_model, t->n_heads);
+    if (t->n_layers <= 0 || t->ffn_hidden <= 0 || (t->ffn_hidden % 64))
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_trunk: bad n_layers/ffn_hidden");
+    if (!(t->residual_scale > 0.f)) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk: residual_scale must be > 0");
+    return ESMK_OK;
+}
+
+}  // namespace
+
+extern "C" size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens) {
+    if (validate_trunk(t) != ESMK_OK || n_tokens <= 0) return 0;
+    return trunk_layout(t, n_tokens).total;
+}
+
+#define TRY(call)                 \
+    do {                          \
+        int rc__ = (call);        \
+        if (rc__ != ESMK_OK) return rc__; \
+    } while (0)
+
+extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
+                                  void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
+    TRY(validate_trunk(t));
+    if (!b || !x) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null batch or x");
+    const int M = b->n_tokens, d = t->d_model, H = t->n_heads, h = t->ffn_hidden;
+    if (M < 0 || b->n_segments < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: bad batch sizes");
+    if (M == 0) return ESMK_OK;
+    if (!b->cu_seqlens || !b->positions || !b->qblk_map || b->n_qblk <= 0)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: batch lacks cu_seqlens/positions/qblk_map");
+    const TrunkWs w = trunk_layout(t, M);
+    if (!workspace || workspace_bytes < w.total)
+        ESMK_FAIL(ESMK_ERR_WORKSPACE, "esmk_trunk_forward: workspace %zu < required %zu", workspace_bytes, w.total);
+    if (((uintptr_t)workspace & 255) || ((uintptr_t)x & 15))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: workspace must be 256-byte and x 16-byte aligned");
+    char* ws = (char*)workspace;
+    void* xn = ws + w.xn;
+    void* qkv = ws + w.qkv;
+    void* ctx = ws + w.ctx;
+    void* hbuf = ws + w.hbuf;
+    const float eps = 1e-5f;
+    const float inv_s = 1.0f / t->residual_scale;
+    const float q_scale = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
+    hipStream_t s = (hipStream_t)stream;
+
+    for (int i = 0; i < t->n_layers; ++i) {
+        const esmk_layer& L = t->layers[i];
+        if (!L.ln1_g || !L.ln1_b || !L.w_qkv || !L.qln_g || !L.kln_g || !L.w_o || !L.ln2_g || !L.ln2_b || !L.w_ffn1 || !L.w_ffn2)
+            ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
+        // --- x += MHA(x) / s  (attention.py:48-82, blocks.py:146-148)
+        TRY(esmk_layernorm(x, ESMK_F32, L.ln1_g, L.ln1_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(esmk_gemm(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, stream));
+        TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
+        TRY(esmk_attn_varlen(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, stream));
+        TRY(esmk_gemm(ctx, d, L.w_o, M, d, d, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
+        // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)
+        if (L.geom_ln_g) {
+            const int vh = t->v_heads;
+            if (vh <= 0 || !L.w_geom_proj || !L.w_geom_out || !L.geom_dist_scale || !L.geom_rot_scale)
+                ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d geometric weights incomplete", i);
+            if (!b->affine || !b->affine_mask || !b->seq_id || !b->chain_id || !b->row_cu)
+                ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: batch lacks geometric-attention inputs");
+            float* gproj = (float*)(ws + w.gproj);
+            void* gout = ws + w.gout;
+            const int ldg = round_up(3 * vh, 64);
+            TRY(esmk_layernorm(x, ESMK_F32, L.geom_ln_g, nullptr, xn, ESMK_BF16, M, d, eps, stream));
+            TRY(esmk_gemm(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, stream));
+            TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
+                               b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
+            TRY(esmk_gemm(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
+        }
+        // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
+        TRY(esmk_layernorm(x, ESMK_F32, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(esmk_gemm(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, stream));
+        TRY(esmk_gemm(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
+        if (hiddens) {
+            if (hipMemcpyAsync(hiddens + (size_t)i * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
+        }
+    }
+    if (post_norm) TRY(esmk_layernorm(x, ESMK_F32, t->final_norm_g, nullptr, post_norm, ESMK_F32, M, d, eps, stream));
+    return ESMK_OK;
+}
+
+extern "C" size_t esmk_head_workspace_bytes(int n_tokens, int d_model) {
+    if (n_tokens <= 0 || d_model <= 0) return 0;
+    return 3 * align256((size_t)n_tokens * d_model * 2);
+}
+
+extern "C" int esmk_head_forward(const esmk_head* hd, const float* x_norm, float* logits, int M, int d, void* workspace,
+                                 size_t workspace_bytes, esmk_stream_t stream) {
+    if (!hd || !x_norm || !logits || !hd->w0 || !hd->b0 || !hd->ln_g || !hd->ln_b || !hd->w3 || !hd->b3)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward: null pointer");
+    if (M < 0 || d <= 0 || (d % 64) || hd->out_dim <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward: bad sizes");
+    if (M == 0) return ESMK_OK;
+    const size_t need = esmk_head_workspace_bytes(M, d);
+    if (!workspace || workspace_bytes < need)
+        ESMK_FAIL(ESMK_ERR_WORKSPACE, "esmk_head_forward: workspace %zu < required %zu", workspace_bytes, need);
+    char* ws = (char*)workspace;
+    const size_t stride = align256((size_t)M * d * 2);
+    void* xb = ws;               // bf16 copy of x_norm
+    void* h0 = ws + stride;      // gelu(x W0^T + b0), bf16
+    void* h1 = ws + 2 * stride;  // LN(h0), bf16
+    // fp32 -> bf16 cast of the post-norm activations = LayerNorm-free copy: reuse the GEMM input path by
+    // running an identity-affine "LayerNorm" is wrong (it would renormalise), so cast with a dedicated pass.
+    TRY(esmk_cast_f32_bf16(x_norm, xb, (size_t)M * d, (hipStream_t)stream));
+    TRY(esmk_gemm(xb, d, hd->w0, M, d, d, ESMK_EPI_BIAS_GELU, hd->b0, 1.f, h0, stream));
+    TRY(esmk_layernorm(h0, ESMK_BF16, hd->ln_g, hd->ln_b, h1, ESMK_BF16, M, d, 1e-5f, stream));
+    TRY(esmk_gemm(h1, d, hd->w3, M, hd->out_dim, d, ESMK_EPI_F32, hd->b3, 1.f, logits, stream));
+    return ESMK_OK;
+}
+
+namespace {
+__global__ void cast_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const f32x4 v = *(const f32x4*)(in + i * 4);
+    u32x2 p;
+    p.x = pack_bf16x2(v[0], v[1]);
+    p.y = pack_bf16x2(v[2], v[3]);
+    *(u32x2*)(out + i * 4) = p;
+}
+}  // namespace
+
+int esmk_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s) {
+    const size_t n4 = n / 4;  // callers pass multiples of 4 (d % 64 == 0)
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, (__bf16*)out, n4);
+    ESMK_CHECK_LAUNCH("esmk_cast_f32_bf16");
+    return ESMK_OK;
+}

@@ -1,0 +1,187 @@
+"""Device-side engine: packed weights + one C call per trunk forward.
+
+torch is used for device memory, the current HIP stream and tensor views only.  All arithmetic on the
+hot path happens inside libesmk.so (hand-written gfx950 kernels); there is no torch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .packing import PackedBatch
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def rotary_tables(n_pos: int, dim: int = 64, base: float = 10000.0):
+    """fp32 cos/sin tables computed exactly as the reference does (esm/layers/rotary.py:136-177)."""
+    inv_freq = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    t = torch.arange(n_pos, dtype=torch.float32)
+    freqs = torch.outer(t, inv_freq)
+    return torch.cos(freqs).contiguous(), torch.sin(freqs).contiguous()
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+def pack_weight(w: torch.Tensor, device, mode: int = L.PACK_PLAIN) -> torch.Tensor:
+    """fp32 [N, K] -> bf16 MFMA layout (esmk_pack_weight)."""
+    lib = L.lib()
+    w = _f32(w, device)
+    N, K = w.shape
+    nbytes = lib.esmk_packed_weight_bytes(N, K)
+    out = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=device)
+    L.check(lib.esmk_pack_weight(L.ptr(w), L.ptr(out), N, K, mode, _stream()), "esmk_pack_weight")
+    return out
+
+
+class DeviceBatch:
+    """PackedBatch uploaded to the device + the esmk_batch descriptor."""
+
+    def __init__(self, pb: PackedBatch, device, affine=None, affine_mask=None, chain_id=None):
+        self.pb = pb
+        i32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(device)
+        self.cu_seqlens = i32(pb.cu_seqlens)
+        self.positions = i32(pb.positions)
+        self.qblk_map = i32(pb.qblk_map.reshape(-1))
+        self.row_cu = i32(pb.row_cu)
+        self.seq_id = i32(pb.seq_id)
+        self.affine = affine  # f32 [N, 12] on device or None
+        self.affine_mask = affine_mask  # uint8 [N]
+        self.chain_id = chain_id  # int32 [N]
+        d = L.EsmkBatch()
+        d.n_tokens = pb.n_tokens
+        d.n_segments = pb.n_segments
+        d.cu_seqlens = L.ptr(self.cu_seqlens)
+        d.positions = L.ptr(self.positions)
+        d.qblk_map = L.ptr(self.qblk_map)
+        d.n_qblk = int(pb.qblk_map.shape[0])
+        d.affine = L.ptr(affine)
+        d.affine_mask = L.ptr(affine_mask)
+        d.seq_id = L.ptr(self.seq_id)
+        d.chain_id = L.ptr(chain_id)
+        d.row_cu = L.ptr(self.row_cu)
+        d.n_rows = pb.B
+        d.max_row_len = pb.max_row_len
+        self.desc = d
+
+
+class TrunkEngine:
+    """Packed TransformerStack weights (reference key names) + esmk_trunk_forward."""
+
+    def __init__(self, weights: dict, prefix: str, d_model: int, n_heads: int, n_layers: int, device,
+                 v_heads: int | None = None, n_layers_geom: int = 0, scale_residue: bool = True,
+                 expansion_ratio: float = 8 / 3, rope_len: int = 4096):
+        if d_model != 64 * n_heads:
+            raise L.EsmkError(f"head dim must be 64 (d_model={d_model}, n_heads={n_heads})")
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self.d, self.H, self.n_layers = d_model, n_heads, n_layers
+        self.v_heads = v_heads or 0
+        self.h = int(((expansion_ratio * d_model) + 255) // 256 * 256)
+        self._keep = []  # device tensors referenced by raw pointers
+        self._layers = (L.EsmkLayer * n_layers)()
+        dev = self.device
+
+        def f(name):
+            t = _f32(weights[prefix + name], dev)
+            self._keep.append(t)
+            return L.ptr(t)
+
+        def p(name, mode=L.PACK_PLAIN):
+            t = pack_weight(weights[prefix + name], dev, mode)
+            self._keep.append(t)
+            return L.ptr(t)
+
+        for i in range(n_layers):
+            b = f"blocks.{i}."
+            ly = self._layers[i]
+            ly.ln1_g, ly.ln1_b = f(b + "attn.layernorm_qkv.0.weight"), f(b + "attn.layernorm_qkv.0.bias")
+            ly.w_qkv = p(b + "attn.layernorm_qkv.1.weight")
+            ly.qln_g, ly.kln_g = f(b + "attn.q_ln.weight"), f(b + "attn.k_ln.weight")
+            ly.w_o = p(b + "attn.out_proj.weight")
+            ly.ln2_g, ly.ln2_b = f(b + "ffn.0.weight"), f(b + "ffn.0.bias")
+            ly.w_ffn1 = p(b + "ffn.1.weight", L.PACK_SWIGLU)
+            ly.w_ffn2 = p(b + "ffn.3.weight")
+            if i < n_layers_geom:
+                ly.geom_ln_g = f(b + "geom_attn.s_norm.weight")
+                ly.w_geom_proj = p(b + "geom_attn.proj.weight")
+                ly.w_geom_out = p(b + "geom_attn.out_proj.weight")
+                ly.geom_dist_scale = f(b + "geom_attn.distance_scale_per_head")
+                ly.geom_rot_scale = f(b + "geom_attn.rotation_scale_per_head")
+        self._norm = _f32(weights[prefix + "norm.weight"], dev)
+        self._desc = L.EsmkTrunk()
+        t = self._desc
+        t.d_model, t.n_heads, t.n_layers, t.ffn_hidden, t.v_heads = d_model, n_heads, n_layers, self.h, self.v_heads
+        t.residual_scale = math.sqrt(n_layers / 36) if scale_residue else 1.0
+        t.layers = C.cast(self._layers, C.POINTER(L.EsmkLayer))
+        t.final_norm_g = L.ptr(self._norm)
+        self._set_rope(rope_len)
+        self._ws = None
+
+    def _set_rope(self, n_pos: int):
+        cos, sin = rotary_tables(n_pos)
+        self._cos, self._sin = cos.to(self.device), sin.to(self.device)
+        self._desc.rope_cos, self._desc.rope_sin, self._desc.rope_len = L.ptr(self._cos), L.ptr(self._sin), n_pos
+
+    def workspace(self, n_tokens: int) -> torch.Tensor:
+        need = self.lib.esmk_trunk_workspace_bytes(C.byref(self._desc), n_tokens)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward(self, x: torch.Tensor, batch: DeviceBatch, want_post: bool = True, want_hiddens: bool = False):
+        """x f32 [N, d] (modified in place -> pre-norm output).  Returns (post_norm|None, x, hiddens|None)."""
+        N = batch.pb.n_tokens
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape == (N, self.d)
+        if batch.pb.max_position >= self._desc.rope_len:
+            self._set_rope(max(2 * self._desc.rope_len, batch.pb.max_position + 1))
+        post = torch.empty_like(x) if want_post else None
+        hid = torch.empty((self.n_layers, N, self.d), dtype=torch.float32, device=x.device) if want_hiddens else None
+        if N == 0:
+            return post, x, hid
+        ws = self.workspace(N)
+        rc = self.lib.esmk_trunk_forward(C.byref(self._desc), C.byref(batch.desc), L.ptr(x), L.ptr(post), L.ptr(hid),
+                                         L.ptr(ws), ws.numel(), _stream())
+        L.check(rc, "esmk_trunk_forward")
+        return post, x, hid
+
+
+class HeadEngine:
+    """RegressionHead (reference esm/layers/regression_head.py:17-22) on esmk_head_forward."""
+
+    def __init__(self, weights: dict, prefix: str, d_model: int, out_dim: int, device):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self.d, self.out_dim = d_model, out_dim
+        self._keep = [
+            pack_weight(weights[prefix + "0.weight"], device), _f32(weights[prefix + "0.bias"], device),
+            _f32(weights[prefix + "2.weight"], device), _f32(weights[prefix + "2.bias"], device),
+            pack_weight(weights[prefix + "3.weight"], device), _f32(weights[prefix + "3.bias"], device),
+        ]
+        h = L.EsmkHead()
+        h.w0, h.b0, h.ln_g, h.ln_b, h.w3, h.b3 = [L.ptr(t) for t in self._keep]
+        h.out_dim = out_dim
+        self._desc = h
+        self._ws = None
+
+    def forward(self, x_norm: torch.Tensor) -> torch.Tensor:
+        N = x_norm.shape[0]
+        assert x_norm.is_cuda and x_norm.dtype == torch.float32 and x_norm.is_contiguous()
+        out = torch.empty((N, self.out_dim), dtype=torch.float32, device=x_norm.device)
+        if N == 0:
+            return out
+        need = self.lib.esmk_head_workspace_bytes(N, self.d)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        rc = self.lib.esmk_head_forward(C.byref(self._desc), L.ptr(x_norm), L.ptr(out), N, self.d, L.ptr(self._ws),
+                                        self._ws.numel(), _stream())
+        L.check(rc, "esmk_head_forward")
+        return out

@@ -1,0 +1,202 @@
+"""ESM3 forward / logits with the reference's Python surface (reference esm/models/esm3.py:50-178,
+260-374,503-559) on the HIP trunk: 8-track input encoder, backbone frames, 48-block stack whose first
+block has geometric attention, six regression heads.  generate/encode/decode are out of scope.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .affine3d import build_affine3d_from_coordinates
+from .api import ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
+from .engine import HeadEngine, _f32, _stream
+from .esmc import RegressionHeadParams
+from .transformer_stack import TransformerStack
+
+# esm/utils/constants/esm3.py:7-39
+SEQUENCE_BOS_TOKEN, SEQUENCE_PAD_TOKEN, SEQUENCE_EOS_TOKEN, SEQUENCE_CHAINBREAK_TOKEN, SEQUENCE_MASK_TOKEN = 0, 1, 2, 31, 32
+STRUCTURE_MASK_TOKEN, STRUCTURE_EOS_TOKEN, STRUCTURE_BOS_TOKEN, STRUCTURE_PAD_TOKEN, STRUCTURE_CHAINBREAK_TOKEN = \
+    4096, 4097, 4098, 4099, 4100
+SS8_PAD_TOKEN = SASA_PAD_TOKEN = INTERPRO_PAD_TOKEN = RESIDUE_PAD_TOKEN = 0
+
+_HEADS = (("sequence_head", 64), ("structure_head", 4096), ("ss8_head", 11), ("sasa_head", 19),
+          ("function_head", 260 * 8), ("residue_head", 1478))
+
+
+@dataclass
+class ESMOutput:
+    sequence_logits: torch.Tensor
+    structure_logits: torch.Tensor
+    secondary_structure_logits: torch.Tensor
+    sasa_logits: torch.Tensor
+    function_logits: torch.Tensor
+    residue_logits: torch.Tensor
+    embeddings: torch.Tensor
+
+
+class EncodeInputs(nn.Module):
+    """Parameter container with the reference's keys (esm3.py:69-90); arithmetic in esmk_esm3_encode."""
+
+    def __init__(self, d_model: int):
+        super().__init__()
+        self.sequence_embed = nn.Embedding(64, d_model)
+        self.plddt_projection = nn.Linear(16, d_model)
+        self.structure_per_res_plddt_projection = nn.Linear(16, d_model)
+        self.structure_tokens_embed = nn.Embedding(4096 + 5, d_model)
+        self.ss8_embed = nn.Embedding(8 + 3, d_model)
+        self.sasa_embed = nn.Embedding(16 + 3, d_model)
+        self.function_embed = nn.ModuleList([nn.Embedding(260, d_model // 8, padding_idx=0) for _ in range(8)])
+        self.residue_embed = nn.EmbeddingBag(1478, d_model, mode="sum", padding_idx=0)
+
+
+class OutputHeads(nn.Module):
+    def __init__(self, d_model: int):
+        super().__init__()
+        for name, dim in _HEADS:
+            setattr(self, name, RegressionHeadParams(d_model, dim))
+
+
+class ESM3(nn.Module):
+    def __init__(self, d_model: int, n_heads: int, v_heads: int, n_layers: int, structure_encoder_fn=None,
+                 structure_decoder_fn=None, function_decoder_fn=None, tokenizers=None):
+        super().__init__()
+        self.encoder = EncodeInputs(d_model)
+        self.transformer = TransformerStack(d_model, n_heads, v_heads, n_layers, mask_and_zero_frameless=True)
+        self.output_heads = OutputHeads(d_model)
+        self.tokenizers = tokenizers or SimpleNamespace(sequence=SimpleNamespace(mask_token_id=SEQUENCE_MASK_TOKEN))
+        self.d_model = d_model
+        self._enc = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
+
+    def _invalidate(self):
+        self._enc = None
+
+    def _apply(self, fn, *a, **k):
+        self._invalidate()
+        return super()._apply(fn, *a, **k)
+
+    @property
+    def device(self):
+        return self.encoder.sequence_embed.weight.device
+
+    @property
+    def raw_model(self):
+        return self
+
+    def _engines(self):
+        if self._enc is None:
+            dev = self.device
+            if dev.type != "cuda":
+                raise L.EsmkError("esm_amd runs on the GPU only: move the model to cuda (there is no CPU path)")
+            e = self.encoder
+            keep = [
+                _f32(e.sequence_embed.weight, dev), _f32(e.plddt_projection.weight, dev),
+                _f32(e.plddt_projection.bias, dev), _f32(e.structure_per_res_plddt_projection.weight, dev),
+                _f32(e.structure_per_res_plddt_projection.bias, dev), _f32(e.structure_tokens_embed.weight, dev),
+                _f32(e.ss8_embed.weight, dev), _f32(e.sasa_embed.weight, dev),
+                torch.stack([_f32(m.weight, dev) for m in e.function_embed]).contiguous(),
+                _f32(e.residue_embed.weight, dev),
+            ]
+            desc = L.EsmkEsm3Encoder(*[L.ptr(t) for t in keep])
+            sd = dict(self.output_heads.state_dict())
+            heads = {name: HeadEngine(sd, name + ".", self.d_model, dim, dev) for name, dim in _HEADS}
+            self._enc = (desc, keep, heads)
+        return self._enc
+
+    @torch.no_grad()
+    def forward(self, *, sequence_tokens=None, structure_tokens=None, ss8_tokens=None, sasa_tokens=None,
+                function_tokens=None, residue_annotation_tokens=None, average_plddt=None, per_res_plddt=None,
+                structure_coords=None, chain_id=None, sequence_id=None) -> ESMOutput:
+        try:
+            Bx, Ln, device = next((x.shape[0], x.shape[1], x.device) for x in
+                                  [sequence_tokens, structure_tokens, ss8_tokens, sasa_tokens, structure_coords,
+                                   function_tokens, residue_annotation_tokens] if x is not None)
+        except StopIteration:
+            raise ValueError("At least one of the inputs must be non-None")
+        B = max(x.shape[0] for x in [sequence_tokens, structure_tokens, ss8_tokens, sasa_tokens, structure_coords,
+                                     function_tokens, residue_annotation_tokens, chain_id, sequence_id]
+                if x is not None)
+
+        def defaults(x, tok, dtype=torch.long):
+            return torch.full((1, Ln), tok, dtype=dtype, device=device) if x is None else x
+
+        def bcast(x, tail=()):  # defaults are built with batch 1 in the reference and broadcast in the sum
+            return x.expand(B, Ln, *tail).contiguous()
+
+        sequence_tokens = defaults(sequence_tokens, self.tokenizers.sequence.mask_token_id)
+        ss8_tokens = defaults(ss8_tokens, SS8_PAD_TOKEN)
+        sasa_tokens = defaults(sasa_tokens, SASA_PAD_TOKEN)
+        average_plddt = defaults(average_plddt, 1).float()
+        if average_plddt.ndim == 0:  # ESM3.logits passes a scalar tensor (esm3.py:534)
+            average_plddt = average_plddt.reshape(1, 1).expand(1, Ln)
+        per_res_plddt = defaults(per_res_plddt, 0).float()
+        chain_id = defaults(chain_id, 0)
+        if residue_annotation_tokens is None:
+            residue_annotation_tokens = torch.full((1, Ln, 16), RESIDUE_PAD_TOKEN, dtype=torch.long, device=device)
+        if function_tokens is None:
+            function_tokens = torch.full((1, Ln, 8), INTERPRO_PAD_TOKEN, dtype=torch.long, device=device)
+        if structure_coords is None:
+            structure_coords = torch.full((1, Ln, 3, 3), float("nan"), dtype=torch.float, device=device)
+        structure_coords = structure_coords[..., :3, :]
+        affine, affine_mask = build_affine3d_from_coordinates(bcast(structure_coords, (3, 3)))
+        structure_tokens = defaults(structure_tokens, STRUCTURE_MASK_TOKEN)
+        structure_tokens = (
+            bcast(structure_tokens).masked_fill(bcast(structure_tokens) == -1, STRUCTURE_MASK_TOKEN)
+            .masked_fill(bcast(sequence_tokens) == SEQUENCE_BOS_TOKEN, STRUCTURE_BOS_TOKEN)
+            .masked_fill(bcast(sequence_tokens) == SEQUENCE_PAD_TOKEN, STRUCTURE_PAD_TOKEN)
+            .masked_fill(bcast(sequence_tokens) == SEQUENCE_EOS_TOKEN, STRUCTURE_EOS_TOKEN)
+            .masked_fill(bcast(sequence_tokens) == SEQUENCE_CHAINBREAK_TOKEN, STRUCTURE_CHAINBREAK_TOKEN))
+
+        desc, _keep, heads = self._engines()
+        ranges = ((sequence_tokens, 64, "sequence_tokens"), (structure_tokens, 4101, "structure_tokens"),
+                  (ss8_tokens, 11, "ss8_tokens"), (sasa_tokens, 19, "sasa_tokens"),
+                  (function_tokens, 260, "function_tokens"), (residue_annotation_tokens, 1478, "residue_annotation_tokens"))
+        for t, n, name in ranges:
+            if int(t.min()) < 0 or int(t.max()) >= n:
+                raise IndexError(f"{name} out of range [0, {n})")
+        M = B * Ln
+        x = torch.empty((M, self.d_model), dtype=torch.float32, device=device)
+        i64 = lambda t, tail=(): bcast(t.to(torch.int64), tail).reshape(M, *tail)
+        f32 = lambda t: bcast(t.to(torch.float32)).reshape(M)
+        args = [i64(sequence_tokens), i64(structure_tokens), f32(average_plddt), f32(per_res_plddt), i64(ss8_tokens),
+                i64(sasa_tokens), i64(function_tokens, (8,)), i64(residue_annotation_tokens, (16,))]
+        import ctypes as C
+        L.check(L.lib().esmk_esm3_encode(C.byref(desc), *[L.ptr(a) for a in args], L.ptr(x), M, self.d_model,
+                                         _stream()), "esmk_esm3_encode")
+        post, pre, _ = self.transformer(x.view(B, Ln, self.d_model),
+                                        None if sequence_id is None else bcast(sequence_id), affine, affine_mask,
+                                        bcast(chain_id))
+        pn = post.reshape(M, self.d_model)
+        out = {name: heads[name].forward(pn).view(B, Ln, -1) for name, _ in _HEADS}
+        return ESMOutput(
+            sequence_logits=out["sequence_head"], structure_logits=out["structure_head"],
+            secondary_structure_logits=out["ss8_head"], sasa_logits=out["sasa_head"],
+            function_logits=out["function_head"].view(B, Ln, 8, 260), residue_logits=out["residue_head"],
+            embeddings=pre)
+
+    def logits(self, input: ESMProteinTensor | _BatchedESMProteinTensor,
+               config: LogitsConfig = LogitsConfig()) -> LogitsOutput:
+        """reference esm3.py:503-559."""
+        if not isinstance(input, _BatchedESMProteinTensor):
+            input = _BatchedESMProteinTensor.from_protein_tensor(input)
+        per_res_plddt = None
+        if input.coordinates is not None:
+            per_res_plddt = input.coordinates.isfinite().all(dim=-1).any(dim=-1).float()
+        o = self.forward(sequence_tokens=input.sequence, structure_tokens=input.structure,
+                         ss8_tokens=input.secondary_structure, sasa_tokens=input.sasa, function_tokens=input.function,
+                         residue_annotation_tokens=input.residue_annotations,
+                         average_plddt=torch.tensor(1.0, device=input.device), per_res_plddt=per_res_plddt,
+                         structure_coords=input.coordinates, chain_id=None, sequence_id=None)
+        return LogitsOutput(
+            logits=ForwardTrackData(
+                sequence=o.sequence_logits if config.sequence else None,
+                structure=o.structure_logits if config.structure else None,
+                secondary_structure=o.secondary_structure_logits if config.secondary_structure else None,
+                sasa=o.sasa_logits if config.sasa else None,
+                function=o.function_logits if config.function else None),
+            residue_annotation_logits=o.residue_logits if config.residue_annotations else None,
+            embeddings=o.embeddings if config.return_embeddings else None)

@@ -1,0 +1,126 @@
+"""TransformerStack with the reference's constructor, state_dict keys and forward contract
+(reference esm/layers/transformer_stack.py:10-94, blocks.py:51-157, attention.py:15-46,
+geom_attention.py:10-50) running on the HIP trunk engine.
+
+The torch sub-modules below are parameter CONTAINERS only - they exist so that `load_state_dict` accepts
+the reference's checkpoints unchanged.  Their forward() is never called; the arithmetic is in libesmk.so.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .affine3d import Affine3D
+from .engine import DeviceBatch, TrunkEngine
+from .packing import PackedBatch, pack_sequence_id
+
+
+def swiglu_correction_fn(expansion_ratio: float, d_model: int) -> int:
+    return int(((expansion_ratio * d_model) + 255) // 256 * 256)
+
+
+class _Params(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise L.EsmkError("parameter container: the forward pass runs in the HIP engine")
+
+
+class _Attn(_Params):
+    def __init__(self, d):
+        super().__init__()
+        self.layernorm_qkv = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 3 * d, bias=False))
+        self.out_proj = nn.Linear(d, d, bias=False)
+        self.q_ln = nn.LayerNorm(d, bias=False)
+        self.k_ln = nn.LayerNorm(d, bias=False)
+
+
+class _Geom(_Params):
+    def __init__(self, d, v_heads):
+        super().__init__()
+        self.s_norm = nn.LayerNorm(d, bias=False)
+        self.proj = nn.Linear(d, 15 * v_heads, bias=False)
+        self.out_proj = nn.Linear(3 * v_heads, d, bias=False)
+        self.distance_scale_per_head = nn.Parameter(torch.zeros(v_heads))
+        self.rotation_scale_per_head = nn.Parameter(torch.zeros(v_heads))
+
+
+class _Block(_Params):
+    def __init__(self, d, h, v_heads, geom):
+        super().__init__()
+        self.attn = _Attn(d)
+        if geom:
+            self.geom_attn = _Geom(d, v_heads)
+        self.ffn = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 2 * h, bias=False), nn.Identity(),
+                                 nn.Linear(h, d, bias=False))
+
+
+class TransformerStack(nn.Module):
+    def __init__(self, d_model: int, n_heads: int, v_heads: int | None, n_layers: int, n_layers_geom: int = 1,
+                 scale_residue: bool = True, mask_and_zero_frameless: bool = False, bias: bool = False,
+                 qk_layernorm: bool = True, ffn_type: str = "swiglu", expansion_ratio: float = 8 / 3,
+                 use_flash_attn: bool = False):
+        super().__init__()
+        if bias or not qk_layernorm or ffn_type != "swiglu":
+            raise NotImplementedError("esm_amd builds the ESM C / ESM3 trunk variant only: bias=False, "
+                                      "qk_layernorm=True, ffn_type='swiglu' (SURVEY.md 8f lists the others as next)")
+        if n_layers_geom > 0 and not mask_and_zero_frameless:
+            raise NotImplementedError("geometric attention is built with mask_and_zero_frameless=True (ESM3)")
+        if n_layers_geom > 0 and v_heads is None:
+            raise ValueError("v_heads must be specified when use_geom_attn is True")
+        self.d_model, self.n_heads, self.v_heads, self.n_layers = d_model, n_heads, v_heads, n_layers
+        self.n_layers_geom, self.scale_residue, self.expansion_ratio = n_layers_geom, scale_residue, expansion_ratio
+        h = swiglu_correction_fn(expansion_ratio, d_model)
+        self.blocks = nn.ModuleList([_Block(d_model, h, v_heads, i < n_layers_geom) for i in range(n_layers)])
+        self.norm = nn.LayerNorm(d_model, bias=False)
+        self._engine = None
+        self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
+
+    # -- engine lifetime ---------------------------------------------------------------------------
+    def _invalidate(self):
+        self._engine = None
+
+    def _apply(self, fn, *a, **k):
+        self._engine = None
+        return super()._apply(fn, *a, **k)
+
+    def engine(self) -> TrunkEngine:
+        if self._engine is None:
+            dev = self.norm.weight.device
+            if dev.type != "cuda":
+                raise L.EsmkError("esm_amd runs on the GPU only: move the module to cuda (there is no CPU path)")
+            self._engine = TrunkEngine(dict(self.state_dict()), "", self.d_model, self.n_heads, self.n_layers, dev,
+                                       v_heads=self.v_heads, n_layers_geom=self.n_layers_geom,
+                                       scale_residue=self.scale_residue, expansion_ratio=self.expansion_ratio)
+        return self._engine
+
+    # -- packed entry point (ESMC / the data-parallel runner) --------------------------------------
+    def forward_packed(self, x: torch.Tensor, batch: DeviceBatch, want_post=True, want_hiddens=False):
+        return self.engine().forward(x, batch, want_post, want_hiddens)
+
+    # -- reference signature -----------------------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, sequence_id: torch.Tensor | None = None, affine: Affine3D | None = None,
+                affine_mask: torch.Tensor | None = None, chain_id: torch.Tensor | None = None):
+        """x [B, L, d] -> (post_norm, pre_norm, hiddens) in fp32 (transformer_stack.py:64-94)."""
+        *batch_dims, d = x.shape
+        if len(batch_dims) != 2:
+            raise ValueError("x must be [B, L, d]")
+        B, Ln = batch_dims
+        dev = x.device
+        sid_np = None if sequence_id is None else sequence_id.detach().cpu().numpy()
+        pb = pack_sequence_id(sid_np, B, Ln, drop_false=False)
+        aff = am = ch = None
+        if self.n_layers_geom > 0:
+            if affine is None or affine_mask is None:
+                raise ValueError("affine and affine_mask are required by the geometric-attention block")
+            at = affine.tensor if isinstance(affine, Affine3D) else affine
+            aff = at.to(torch.float32).reshape(B * Ln, 12).contiguous()
+            am = affine_mask.reshape(B * Ln).to(torch.uint8).contiguous()
+            if chain_id is None:
+                chain_id = torch.ones((B, Ln), dtype=torch.int64, device=dev)
+            ch = chain_id.reshape(B * Ln).to(torch.int32).contiguous()
+        batch = DeviceBatch(pb, dev, aff, am, ch)
+        xf = x.to(torch.float32).reshape(B * Ln, d).clone()
+        post, pre, hid = self.engine().forward(xf, batch, want_post=True, want_hiddens=True)
+        hiddens = [hid[i].view(B, Ln, d) for i in range(self.n_layers)]
+        return post.view(B, Ln, d), pre.view(B, Ln, d), hiddens

@@ -1,0 +1,235 @@
+/*
+ * esmk.h - C ABI of the MI355X (gfx950) transformer-trunk kernels.
+ *
+ * This is the drop-in boundary for the ESM C / ESM3 trunk forward.  The reference has no
+ * FFI of its own: its seam is the nn.Module boundary plus the optional third-party
+ * flash-attn operators selected by `use_flash_attn` (reference esm/layers/blocks.py:90-98,
+ * esm/layers/attention.py:10-13,117-119, esm/layers/rotary.py:246-261, esm/models/esmc.py:142-164).
+ * Every entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, explicit sizes, a HIP stream passed as void*; no torch types.
+ *   - every function returns 0 on success, <0 on error (ESMK_ERR_*); esmk_last_error() gives text.
+ *     Nothing throws, aborts or exits.  Shapes are validated on the host before any launch.
+ *   - the caller owns every buffer; nothing here allocates device memory or synchronises the device.
+ *   - work is enqueued on `stream` and is ordered with other work on that stream.
+ *   - activations: packed tokens, row-major [n_tokens, width]; no row padding is required.
+ *   - "packed weight": bf16 [round_up(N,128), round_up(K,64)] produced by esmk_pack_weight.
+ */
+#ifndef ESMK_H
+#define ESMK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ESMK_VERSION 100
+
+#define ESMK_OK 0
+#define ESMK_ERR_INVALID_ARG (-1)
+#define ESMK_ERR_UNSUPPORTED (-2)
+#define ESMK_ERR_LAUNCH (-3)
+#define ESMK_ERR_WORKSPACE (-4)
+
+/* element types of activation buffers */
+#define ESMK_F32 0
+#define ESMK_BF16 1
+
+typedef void* esmk_stream_t; /* hipStream_t */
+
+int esmk_version(void);
+const char* esmk_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Weight packing (once per model).
+ * Replaces: nothing at run time; consumes the reference state_dict tensors (fp32 [N,K] row-major,
+ * SURVEY.md 8b) and lays them out for the MFMA GEMM: bf16, rows padded to 128, K padded to 64.
+ * mode ESMK_PACK_SWIGLU interleaves the gate rows [0,N/2) and up rows [N/2,N) of ffn.1.weight
+ * (reference esm/layers/blocks.py:26-27) in groups of 16 so one MFMA tile pair owns gate+up of the
+ * same channels.
+ * ------------------------------------------------------------------------------------------ */
+#define ESMK_PACK_PLAIN 0
+#define ESMK_PACK_SWIGLU 1
+size_t esmk_packed_weight_bytes(int N, int K);
+int esmk_pack_weight(const float* w_f32, void* packed, int N, int K, int mode, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * LayerNorm over the last dim (eps inside sqrt, biased variance - torch.nn.LayerNorm).
+ * Replaces: nn.LayerNorm in layernorm_qkv[0], ffn[0], transformer.norm, RegressionHead[2],
+ * geom_attn.s_norm (reference esm/layers/attention.py:26-28, blocks.py:31,
+ * transformer_stack.py:62,94, regression_head.py:20, geom_attention.py:38,65).
+ * x [M, d] (x_dtype), y [M, ldy] (y_dtype) written in columns [0, d); beta may be NULL.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
+                   int M, int d, float eps, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM  out = epilogue(A[M,K] . W[N,K]^T)  on bf16 MFMA with fp32 accumulation.
+ * Replaces: every nn.Linear on the path (reference attention.py:27,29,82; blocks.py:32-37;
+ * geom_attention.py:43,45; regression_head.py:18,21) with the op that follows it fused:
+ *   ESMK_EPI_BF16       out bf16 [M,N]            = acc
+ *   ESMK_EPI_F32        out f32  [M,N]            = acc (+ bias if bias != NULL)
+ *   ESMK_EPI_SWIGLU     out bf16 [M,N/2]          = silu(gate) * up       (blocks.py:26-27; W packed SWIGLU)
+ *   ESMK_EPI_RESIDUAL   out f32  [M,N] (in/out)   += alpha * acc           (blocks.py:147-155, alpha = 1/s)
+ *   ESMK_EPI_BIAS_GELU  out bf16 [M,N]            = gelu_erf(acc + bias)   (regression_head.py:18-19)
+ * A: bf16 row-major with leading dimension lda >= round_up(K,64) (pad columns must be zero or finite:
+ * the packed weight is zero there).
+ * ------------------------------------------------------------------------------------------ */
+#define ESMK_EPI_BF16 0
+#define ESMK_EPI_F32 1
+#define ESMK_EPI_SWIGLU 2
+#define ESMK_EPI_RESIDUAL 3
+#define ESMK_EPI_BIAS_GELU 4
+int esmk_gemm(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
+              const float* bias, float alpha, void* out, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * QK-LayerNorm + rotary, in place on the packed qkv buffer.
+ * Replaces: q_ln / k_ln over the FULL d_model width (bias-free) followed by NeoX rotary on every
+ * 64-wide head (reference attention.py:31-33,40-46,51-55; rotary.py:36-65,198-230) and, for the
+ * packed layout, flash-attn's Triton apply_rotary (rotary.py:246-261).
+ * qkv bf16 [M, 3d]: columns [0,d)=q, [d,2d)=k, [2d,3d)=v (attention.py:50), head h = columns h*64..h*64+63.
+ * positions int32 [M]: rotary position of each token (column index in the reference's [B,L] row).
+ * rope_cos / rope_sin f32 [rope_len, 32] (angles computed in fp32 as rotary.py:136-181 does).
+ * q is additionally multiplied by q_scale (softmax scale * log2(e)) so the attention kernel uses exp2.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_qk_prep(void* qkv_bf16, const float* gamma_q, const float* gamma_k, const int32_t* positions,
+                 const float* rope_cos, const float* rope_sin, int rope_len, int M, int d, int n_heads,
+                 float q_scale, float eps, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Varlen packed flash attention (non-causal, block-diagonal by segment), head dim 64.
+ * Replaces: F.scaled_dot_product_attention with the sequence_id equality mask (reference
+ * attention.py:65-78) and flash_attn_varlen_qkvpacked_func(qkv[N,3,H,64], cu_seqlens, max_seqlen,
+ * softmax_scale) -> [N,H,64] (attention.py:117-119).
+ * qkv as produced by esmk_qk_prep (q pre-scaled, so scores feed exp2 directly).
+ * cu_seqlens int32 [n_segments+1] (device).  qblk_map int32 [2*n_qblk] (device) from esmk_attn_plan.
+ * ctx bf16 [M, d].
+ * esmk_attn_plan is HOST-side: it fills qblk_map_host with (segment, first query row in segment)
+ * pairs, 128 query rows per block, and returns the number of blocks (or <0).  Pass NULL to count.
+ * ------------------------------------------------------------------------------------------ */
+#define ESMK_ATTN_QBLK 128
+int esmk_attn_plan(const int32_t* cu_seqlens_host, int n_segments, int32_t* qblk_map_host, int capacity);
+int esmk_attn_varlen(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seqlens, const int32_t* qblk_map,
+                     int n_qblk, int M, int d, int n_heads, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Embedding gather: out f32 [M, d] = table[tokens].   Replaces nn.Embedding (esmc.py:63,137).
+ * ------------------------------------------------------------------------------------------ */
+int esmk_embed(const int64_t* tokens, const float* table, int vocab, float* out, int M, int d,
+               esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ESM3 input encoder: out f32 [M,d] = sum of the 8 track embeddings.
+ * Replaces EncodeInputs.forward + rbf (reference esm/models/esm3.py:92-147, esm/utils/misc.py:105-115).
+ * function_tokens int64 [M,8], residue_tokens int64 [M,16]; function tables are 8 x [260, d/8]
+ * concatenated; padding index 0 contributes nothing for function/residue tracks.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* sequence_embed;  /* [64, d] */
+    const float* plddt_w;         /* [d, 16] */
+    const float* plddt_b;         /* [d] */
+    const float* res_plddt_w;     /* [d, 16] */
+    const float* res_plddt_b;     /* [d] */
+    const float* structure_embed; /* [4101, d] */
+    const float* ss8_embed;       /* [11, d] */
+    const float* sasa_embed;      /* [19, d] */
+    const float* function_embed;  /* [8, 260, d/8] */
+    const float* residue_embed;   /* [1478, d] */
+} esmk_esm3_encoder;
+int esmk_esm3_encode(const esmk_esm3_encoder* enc, const int64_t* sequence, const int64_t* structure,
+                     const float* average_plddt, const float* per_res_plddt, const int64_t* ss8,
+                     const int64_t* sasa, const int64_t* function_tokens, const int64_t* residue_tokens,
+                     float* out, int M, int d, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Backbone frames.  Replaces build_affine3d_from_coordinates (reference
+ * esm/utils/structure/affine3d.py:494-560): Gram-Schmidt frames from (N, CA, C), eps 1e-10,
+ * "black hole" frame for residues without coordinates, identity rotation for rows with none.
+ * coords f32 [B, L, 3, 3]; affine f32 [B*L, 12] = [rot row-major 9 | trans 3]; mask u8 [B*L].
+ * ------------------------------------------------------------------------------------------ */
+int esmk_frames(const float* coords, float* affine, uint8_t* mask, int B, int L, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Geometric attention core (ESM3 block 0).  Replaces GeometricReasoningOriginalImpl.forward steps
+ * (4)-(10) (reference esm/layers/geom_attention.py:52-63,74-146): rotate/translate the projected
+ * 3-vectors into the global frame, scores = rot.dot*softplus(w_r)/sqrt3 - |dist|*softplus(w_d)/sqrt3
+ * + bias, softmax over the keys of the same batch row, P.V, inverse rotation, zero frameless rows.
+ * proj f32 [M, 15*H] (s_norm + proj GEMM output).  row_cu int32 [n_rows+1]: token ranges of the
+ * reference's batch rows.  seq_id / chain_id int32 [M].  out bf16 [M, ld_out], columns [0,3H)
+ * written, [3H, ld_out) zeroed (ld_out = round_up(3H,64), feeds esmk_gemm).
+ * scratch: f32, esmk_geom_scratch_bytes(M, H) bytes.
+ * ------------------------------------------------------------------------------------------ */
+size_t esmk_geom_scratch_bytes(int M, int v_heads);
+int esmk_geom_attn(const float* proj, const float* affine, const uint8_t* affine_mask, const int32_t* seq_id,
+                   const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
+                   const float* dist_scale, const float* rot_scale, void* out_bf16, int ld_out, void* scratch,
+                   int M, int v_heads, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole trunk in one call.  Replaces TransformerStack.forward (reference
+ * esm/layers/transformer_stack.py:64-94) = n_layers x UnifiedTransformerBlock.forward
+ * (blocks.py:146-157) + the final bias-free LayerNorm.
+ * x f32 [M, d] is the residual stream: input embeddings in, PRE-norm output out.
+ * post_norm f32 [M, d] receives norm(x).  hiddens (optional, may be NULL) f32 [n_layers, M, d].
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* ln1_g; const float* ln1_b; /* attn.layernorm_qkv.0 */
+    const void* w_qkv;                      /* packed [3d, d] */
+    const float* qln_g; const float* kln_g; /* attn.q_ln / attn.k_ln */
+    const void* w_o;                        /* packed [d, d] */
+    const float* ln2_g; const float* ln2_b; /* ffn.0 */
+    const void* w_ffn1;                     /* packed SWIGLU [2h, d] */
+    const void* w_ffn2;                     /* packed [d, h] */
+    /* geometric attention; geom_ln_g == NULL when the block has none */
+    const float* geom_ln_g;                 /* geom_attn.s_norm.weight */
+    const void* w_geom_proj;                /* packed [15*v_heads, d] */
+    const void* w_geom_out;                 /* packed [d, 3*v_heads] */
+    const float* geom_dist_scale; const float* geom_rot_scale; /* [v_heads] */
+} esmk_layer;
+
+typedef struct {
+    int d_model, n_heads, n_layers, ffn_hidden, v_heads;
+    float residual_scale;          /* s = sqrt(n_layers/36) */
+    const esmk_layer* layers;      /* HOST array of n_layers */
+    const float* final_norm_g;     /* transformer.norm.weight */
+    const float* rope_cos; const float* rope_sin; int rope_len;
+} esmk_trunk;
+
+typedef struct {
+    int n_tokens, n_segments;
+    const int32_t* cu_seqlens;     /* device [n_segments+1] */
+    const int32_t* positions;      /* device [n_tokens] */
+    const int32_t* qblk_map; int n_qblk; /* device, from esmk_attn_plan */
+    /* geometric attention inputs (may be NULL when no block has geometric attention) */
+    const float* affine; const uint8_t* affine_mask;
+    const int32_t* seq_id; const int32_t* chain_id;
+    const int32_t* row_cu; int n_rows; int max_row_len;
+} esmk_batch;
+
+size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens);
+int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
+                       void* workspace, size_t workspace_bytes, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * RegressionHead: logits f32 [M, out_dim].  Replaces Linear -> GELU -> LayerNorm -> Linear
+ * (reference esm/layers/regression_head.py:17-22).  x_norm f32 [M, d] (post-norm trunk output).
+ * workspace: esmk_head_workspace_bytes(M, d).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const void* w0; const float* b0;  /* packed [d, d], [d] */
+    const float* ln_g; const float* ln_b;
+    const void* w3; const float* b3;  /* packed [out_dim, d], [out_dim] */
+    int out_dim;
+} esmk_head;
+size_t esmk_head_workspace_bytes(int n_tokens, int d_model);
+int esmk_head_forward(const esmk_head* h, const float* x_norm, float* logits, int M, int d, void* workspace,
+                      size_t workspace_bytes, esmk_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESMK_H */

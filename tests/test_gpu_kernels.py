@@ -1,0 +1,177 @@
+"""Per-kernel parity: each C-ABI entry point against a plain torch fp32 computation of the same op on
+identical (bf16-rounded where the kernel consumes bf16) inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _env():
+    from esm_amd import _lib as L
+    from esm_amd import engine
+    return L, L.lib(), engine
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 128), (1000, 3456, 1152), (77, 120, 128), (513, 1152, 3072)])
+def test_gemm_bf16_and_f32(M, N, K):
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = (torch.randn(N, K, generator=g) * 0.05)
+    Wp = engine.pack_weight(W, "cuda")
+    ref = A.float() @ W.bfloat16().float().cuda().T
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_BF16, None, 1.0, out.data_ptr(), _s()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    tol = 0.01 * ref.abs().max().item() + 1e-3
+    assert (out.float() - ref).abs().max().item() <= tol
+    bias = torch.randn(N, generator=g).cuda()
+    out32 = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_F32, bias.data_ptr(), 1.0, out32.data_ptr(), _s()))
+    torch.cuda.synchronize()
+    assert (out32 - (ref + bias)).abs().max().item() <= 2e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_f32_odd_n_and_padded_k():
+    """N not a multiple of 4 (ESM3 ss8/sasa heads) and K padded to 64 (geometric out-proj with 3*v_heads=24)."""
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 70, 11, 24
+    A = torch.zeros(M, 64, dtype=torch.bfloat16)
+    A[:, :K] = torch.randn(M, K, generator=g).bfloat16()
+    A = A.cuda()
+    W = torch.randn(N, K, generator=g)
+    Wp = engine.pack_weight(W, "cuda")
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), 64, Wp.data_ptr(), M, N, K, L.EPI_F32, None, 1.0, out.data_ptr(), _s()))
+    ref = A[:, :K].float() @ W.bfloat16().float().cuda().T
+    assert (out - ref).abs().max().item() <= 1e-3 * max(1.0, ref.abs().max().item())
+
+
+def test_gemm_residual_swiglu_gelu():
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(2)
+    M, d, h = 260, 128, 512
+    A = torch.randn(M, d, generator=g).bfloat16().cuda()
+    W1 = torch.randn(2 * h, d, generator=g) * 0.1
+    W1p = engine.pack_weight(W1, "cuda", L.PACK_SWIGLU)
+    y = A.float() @ W1.bfloat16().float().cuda().T
+    ref = torch.nn.functional.silu(y[:, :h]) * y[:, h:]
+    out = torch.empty((M, h), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), d, W1p.data_ptr(), M, 2 * h, d, L.EPI_SWIGLU, None, 1.0, out.data_ptr(), _s()))
+    assert (out.float() - ref).abs().max().item() <= 0.01 * ref.abs().max().item() + 1e-3
+    # residual: x += alpha * (A . W^T)
+    W2 = torch.randn(d, d, generator=g) * 0.1
+    W2p = engine.pack_weight(W2, "cuda")
+    x0 = torch.randn(M, d, generator=g).cuda()
+    x = x0.clone()
+    L.check(lib.esmk_gemm(A.data_ptr(), d, W2p.data_ptr(), M, d, d, L.EPI_RESIDUAL, None, 0.75, x.data_ptr(), _s()))
+    ref = x0 + 0.75 * (A.float() @ W2.bfloat16().float().cuda().T)
+    assert (x - ref).abs().max().item() <= 1e-3
+    # bias + gelu
+    b = torch.randn(d, generator=g).cuda()
+    o = torch.empty((M, d), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), d, W2p.data_ptr(), M, d, d, L.EPI_BIAS_GELU, b.data_ptr(), 1.0, o.data_ptr(), _s()))
+    ref = torch.nn.functional.gelu(A.float() @ W2.bfloat16().float().cuda().T + b)
+    assert (o.float() - ref).abs().max().item() <= 0.01 * ref.abs().max().item() + 1e-3
+
+
+@pytest.mark.parametrize("M,d", [(5, 128), (1000, 1152), (33, 960), (64, 2560)])
+def test_layernorm(M, d):
+    L, lib, _ = _env()
+    g = torch.Generator().manual_seed(d)
+    x = (torch.randn(M, d, generator=g) * 3 + 1).cuda()
+    gam = torch.randn(d, generator=g).cuda()
+    bet = torch.randn(d, generator=g).cuda()
+    ref = torch.nn.functional.layer_norm(x, (d,), gam, bet)
+    y = torch.empty_like(x)
+    L.check(lib.esmk_layernorm(x.data_ptr(), L.F32, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), L.F32, M, d, 1e-5, _s()))
+    assert (y - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    yb = torch.empty((M, d), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_layernorm(x.data_ptr(), L.F32, gam.data_ptr(), None, yb.data_ptr(), L.BF16, M, d, 1e-5, _s()))
+    ref2 = torch.nn.functional.layer_norm(x, (d,), gam, None)
+    assert (yb.float() - ref2).abs().max().item() <= 0.01 * ref2.abs().max().item()
+
+
+def _attention_reference(qkv, cu, H, gq, gk, positions):
+    """fp32 torch: QK-LayerNorm over d, rotary at `positions`, block-diagonal softmax attention."""
+    from oracle import trunk_ref
+    N, d3 = qkv.shape
+    d = d3 // 3
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    q = trunk_ref.layer_norm(q, gq)
+    k = trunk_ref.layer_norm(k, gk)
+    cos, sin = trunk_ref.rotary_tables(int(positions.max()) + 1)
+    c, s = cos[positions][:, None, :], sin[positions][:, None, :]
+
+    def rot(x):
+        x = x.reshape(N, H, 64)
+        x1, x2 = x[..., :32], x[..., 32:]
+        return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s], -1)
+
+    q, k, v = rot(q), rot(k), v.reshape(N, H, 64)
+    out = torch.zeros(N, H, 64)
+    for a, b in zip(cu[:-1], cu[1:]):
+        sc = torch.einsum("ihd,jhd->hij", q[a:b], k[a:b]) / 8.0
+        out[a:b] = torch.einsum("hij,jhd->ihd", torch.softmax(sc, -1), v[a:b])
+    return out.reshape(N, d)
+
+
+@pytest.mark.parametrize("lens,H", [([64], 2), ([1, 7, 130], 2), ([512, 300, 129, 64, 1], 15), ([1000], 3)])
+def test_qk_prep_and_attention(lens, H):
+    L, lib, engine = _env()
+    from esm_amd.packing import pack_lengths
+    d = 64 * H
+    pb = pack_lengths(lens)
+    N = pb.n_tokens
+    g = torch.Generator().manual_seed(N + H)
+    qkv = torch.randn(N, 3 * d, generator=g).bfloat16()
+    gq = 1 + 0.1 * torch.randn(d, generator=g)
+    gk = 1 + 0.1 * torch.randn(d, generator=g)
+    pos = torch.from_numpy(pb.positions.astype(np.int64))
+    ref = _attention_reference(qkv.float(), pb.cu_seqlens.tolist(), H, gq, gk, pos)
+    cos, sin = engine.rotary_tables(int(pos.max()) + 1)
+    dq = qkv.cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
+    positions, cu, qmap = dev(pb.positions), dev(pb.cu_seqlens), dev(pb.qblk_map.reshape(-1))
+    cosd, sind, gqd, gkd = cos.cuda(), sin.cuda(), gq.cuda(), gk.cuda()
+    q_scale = 0.125 * math.log2(math.e)
+    L.check(lib.esmk_qk_prep(dq.data_ptr(), gqd.data_ptr(), gkd.data_ptr(), positions.data_ptr(), cosd.data_ptr(),
+                             sind.data_ptr(), cos.shape[0], N, d, H, q_scale, 1e-5, _s()))
+    ctx = torch.full((N, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_attn_varlen(dq.data_ptr(), ctx.data_ptr(), cu.data_ptr(), qmap.data_ptr(), pb.qblk_map.shape[0],
+                                 N, d, H, _s()))
+    torch.cuda.synchronize()
+    got = ctx.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 0.03 * max(1.0, ref.abs().max().item()), err
+
+
+def test_attn_plan_matches_host_logic():
+    L, lib, _ = _env()
+    from esm_amd.packing import plan_attention
+    cu = np.array([0, 5, 5 + 128, 5 + 128 + 300], dtype=np.int32)
+    n = lib.esmk_attn_plan(cu.ctypes.data, 3, None, 0)
+    buf = np.zeros((n, 2), dtype=np.int32)
+    assert lib.esmk_attn_plan(cu.ctypes.data, 3, buf.ctypes.data, n) == n
+    assert np.array_equal(buf, plan_attention(cu))
+
+
+def test_error_paths_do_not_launch():
+    L, lib, _ = _env()
+    x = torch.zeros(4, 130, device="cuda")
+    rc = lib.esmk_layernorm(x.data_ptr(), L.F32, x.data_ptr(), None, x.data_ptr(), L.F32, 4, 130, 1e-5, _s())
+    assert rc == -2 and b"multiple of 4" in lib.esmk_last_error()
+    rc = lib.esmk_gemm(None, 64, x.data_ptr(), 4, 4, 64, L.EPI_BF16, None, 1.0, x.data_ptr(), _s())
+    assert rc == -1
+    with pytest.raises(L.EsmkError):
+        L.check(rc, "esmk_gemm")

@@ -1,0 +1,137 @@
+"""Model-level parity on the GPU: the HIP path (through the C-ABI) against the golden fixtures produced by
+the imported reference (fp32) - the north_star gate: per-residue embedding cosine >= 0.999 on valid
+positions and logits max|err| <= 0.05 + 0.02*max|logit_ref| (stated bf16 tolerance)."""
+import pytest
+import torch
+
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+COS_MIN = 0.999
+
+
+def logits_ok(got, ref):
+    lim = 0.05 + 0.02 * ref.abs().max().item()
+    err = (got - ref).abs().max().item()
+    assert err <= lim, (err, lim)
+
+
+def emb_ok(got, ref, cos_min=COS_MIN):
+    c = G.cosine_min(got, ref)
+    assert c >= cos_min, c
+    # magnitude check too: cosine alone is scale-blind
+    rel = (got - ref).norm().item() / max(ref.norm().item(), 1e-30)
+    assert rel <= 0.03, rel
+
+
+@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128"])
+def test_esmc_vs_golden(name):
+    from esm_amd.esmc import ESMC
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    m = ESMC(int(fx["d"]), int(fx["H"]), int(fx["NL"]))
+    m.load_state_dict(w)
+    m = m.cuda()
+    tok = G.t(fx["tokens"])
+    sid = G.t(fx["sequence_id"]).cuda() if "sequence_id" in fx else None
+    out = m(tok.cuda(), sequence_id=sid)
+    torch.cuda.synchronize()
+    s = int(fx["token_stride"])
+    valid = (tok != 1)[:, ::s]
+    logits_ok(out.sequence_logits.cpu()[:, ::s][valid], G.t(fx["sequence_logits"])[valid])
+    emb_ok(out.embeddings.cpu()[:, ::s][valid], G.t(fx["embeddings"])[valid])
+    hl = [int(i) for i in fx["hidden_layers"]]
+    hs = out.hidden_states.cpu()[hl][:, :, ::s]
+    for j in range(len(hl)):
+        emb_ok(hs[j][valid], G.t(fx["hidden_states"])[j][valid])
+    if name == "esmc_tiny_bool":  # dropped pads come back as zeros (reference flash path, esmc.py:159-164)
+        assert out.embeddings.cpu()[tok == 1].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560"])
+def test_stack_vs_golden(name):
+    from esm_amd.transformer_stack import TransformerStack
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    m = TransformerStack(int(fx["d"]), int(fx["H"]), None, int(fx["NL"]), n_layers_geom=0)
+    m.load_state_dict(w)
+    m = m.cuda()
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
+    post, pre, hid = m(G.t(fx["x"]).cuda(), None if sid is None else sid.cuda())
+    s = int(fx["token_stride"])
+    valid = sid[:, ::s] if sid is not None else torch.ones(post[:, ::s].shape[:2], dtype=torch.bool)
+    emb_ok(post.cpu()[:, ::s][valid], G.t(fx["post"])[valid])
+    emb_ok(pre.cpu()[:, ::s][valid], G.t(fx["pre"])[valid])
+    assert len(hid) == int(fx["NL"])
+
+
+def test_frames_vs_golden():
+    from esm_amd.affine3d import build_affine3d_from_coordinates
+    fx = G.load("frames")
+    aff, mask = build_affine3d_from_coordinates(G.t(fx["coords"]).cuda())
+    assert torch.equal(mask.cpu(), G.t(fx["mask"]))
+    assert (aff.tensor.cpu() - G.t(fx["affine"])).abs().max().item() <= 2e-5
+
+
+@pytest.mark.parametrize("name", ["esm3_tiny_alltracks", "esm3_tiny_seqstruct", "esm3_tiny_chain_seqid",
+                                  "esm3_d1536_2layer"])
+def test_esm3_vs_golden(name):
+    from esm_amd.esm3 import ESM3
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    m = ESM3(int(fx["d"]), int(fx["H"]), int(fx["VH"]), int(fx["NL"]))
+    m.load_state_dict(w)
+    m = m.cuda()
+    kw = {k: v.cuda() for k, v in G.esm3_kwargs(fx).items()}
+    out = m(**kw)
+    torch.cuda.synchronize()
+    bs = int(fx["big_stride"])
+    emb_ok(out.embeddings.cpu(), G.t(fx["embeddings"]))
+    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits"):
+        logits_ok(getattr(out, k).cpu(), G.t(fx[k]))
+    for k in ("structure_logits", "function_logits", "residue_logits"):
+        logits_ok(getattr(out, k).cpu()[:, ::bs], G.t(fx[k]))
+
+
+@pytest.mark.parametrize("name", ["geom_plain", "geom_nostruct", "geom_multichain", "geom_binpacked",
+                                  "geom_onerow_frameless", "geom_d1536_vh256"])
+def test_geom_core_vs_golden(name):
+    """esmk_geom_attn alone: proj (fp32, computed here from the fixture's s) -> pre-out_proj 3-vectors."""
+    import numpy as np
+    from esm_amd import _lib as L
+    from oracle import trunk_ref
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    p = "blocks.0.geom_attn."
+    VH, d = int(fx["VH"]), int(fx["d"])
+    s = G.t(fx["s"])
+    B, Ln, _ = s.shape
+    M = B * Ln
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else torch.zeros(B, Ln, dtype=torch.int64)
+    proj = (trunk_ref.layer_norm(s, w[p + "s_norm.weight"]) @ w[p + "proj.weight"].T).reshape(M, 15 * VH)
+    lib = L.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    coords = G.t(fx["coords"]).cuda()
+    aff = torch.empty((M, 12), device="cuda")
+    mask = torch.empty((M,), dtype=torch.uint8, device="cuda")
+    L.check(lib.esmk_frames(coords.data_ptr(), aff.data_ptr(), mask.data_ptr(), B, Ln, st))
+    ld = (3 * VH + 63) // 64 * 64
+    out = torch.full((M, ld), float("nan"), dtype=torch.bfloat16, device="cuda")
+    scratch = torch.empty(lib.esmk_geom_scratch_bytes(M, VH), dtype=torch.uint8, device="cuda")
+    i32 = lambda t_: t_.reshape(-1).to(torch.int32).cuda()
+    row_cu = torch.arange(0, M + 1, Ln, dtype=torch.int32).cuda()
+    projd, sidd, chd = proj.cuda(), i32(sid), i32(G.t(fx["chain_id"]))
+    ds, rs = w[p + "distance_scale_per_head"].cuda(), w[p + "rotation_scale_per_head"].cuda()
+    L.check(lib.esmk_geom_attn(projd.data_ptr(), aff.data_ptr(), mask.data_ptr(), sidd.data_ptr(), chd.data_ptr(),
+                               row_cu.data_ptr(), B, Ln, ds.data_ptr(), rs.data_ptr(), out.data_ptr(), ld,
+                               scratch.data_ptr(), M, VH, st))
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    assert got[:, 3 * VH:].abs().max().item() == 0.0 if ld > 3 * VH else True
+    full = got[:, :3 * VH] @ w[p + "out_proj.weight"].T
+    ref = G.t(fx["out"]).reshape(M, d)
+    assert (full - ref).abs().max().item() <= 0.02 * max(ref.abs().max().item(), 1e-3) + 1e-4
+    if name == "geom_nostruct":
+        assert got.abs().max().item() == 0.0
