@@ -1,0 +1,192 @@
+"""Headline benchmark: residues/sec of the ESM C 600M forward at L=512 (BASELINE.json config C2).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+
+A step = one forward (embedding gather -> 36-block trunk -> sequence head) of one packed batch of
+64 x 512 synthetic residues per GPU, inputs resident in HBM.  Weak scaling: every rank runs its own batch
+with replicated weights and no data-path collective; the only collective is the result gather of the
+data-parallel runner (bf16 per-residue embeddings, on a side stream, overlapped with the next step).
+Rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline      dominant kernel = the FFN up-projection GEMM with the SwiGLU epilogue
+                (32768 x 6144 x 1152): algorithmic FLOPs / mean launch time from HIP events on the launch stream,
+                against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md).
+  cpu_baseline  the CPU oracle (fp32 restatement of the reference, oracle/trunk_ref.py) timed on this host's
+                cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+D_MODEL, N_HEADS, N_LAYERS, FFN_H = 1152, 18, 36, 3072
+BATCH, SEQ_LEN = 64, 512
+PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
+
+
+def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
+    """Algorithmic FLOPs (multiply-add = 2), SURVEY.md 8(d): per layer 8d^2 + 6dh + 4Ld, head 2d^2 + 2*d*64."""
+    return layers * (8 * d * d + 6 * d * h + 4 * L * d) + 2 * d * d + 2 * d * 64
+
+
+def time_dominant_kernel(model, n_tokens, iters=20):
+    """Mean launch duration (s) of the FFN1 (SwiGLU) GEMM via HIP events on the current stream."""
+    from esm_amd import _lib as L
+    lib = L.lib()
+    eng = model.transformer.engine()
+    a = (torch.randn(n_tokens, D_MODEL, device="cuda") * 1.0).bfloat16()
+    out = torch.empty(n_tokens, FFN_H, dtype=torch.bfloat16, device="cuda")
+    w = eng._layers[N_LAYERS // 2].w_ffn1
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        L.check(lib.esmk_gemm(a.data_ptr(), D_MODEL, w, n_tokens, 2 * FFN_H, D_MODEL, L.EPI_SWIGLU, None, 1.0,
+                              out.data_ptr(), st))
+    for _ in range(3):
+        run()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / iters
+
+
+def cpu_baseline(weights, n_seqs=4):
+    """Oracle (port of the reference's fp32 path) on a bounded sample: n_seqs x 512 residues, all 36 layers."""
+    from esm_amd import synth
+    from oracle import trunk_ref  # checker / baseline only
+    tok = synth.synth_tokens([SEQ_LEN] * n_seqs, seed=4321)
+    threads = torch.get_num_threads()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        trunk_ref.esmc_forward(tok, weights, N_HEADS, N_LAYERS)
+    dt = time.perf_counter() - t0
+    return {"value": n_seqs * SEQ_LEN / dt, "unit": "residues/s", "cores": threads, "kind": "port",
+            "sample": f"{n_seqs} x {SEQ_LEN} residues, ESM C 600M-shaped fp32, one pass, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from esm_amd import synth
+    from esm_amd.engine import DeviceBatch
+    from esm_amd.esmc import ESMC
+    from esm_amd.packing import pack_lengths
+
+    dev = torch.device("cuda", local_rank)
+    weights = synth.esmc_weights(D_MODEL, N_LAYERS, seed=0)
+    model = ESMC(D_MODEL, N_HEADS, N_LAYERS)
+    model.load_state_dict(weights)
+    model = model.to(dev)
+    model._engines()
+
+    n_tok = BATCH * SEQ_LEN
+    tokens = synth.synth_tokens([SEQ_LEN] * BATCH, seed=1234 + 1000 * rank).reshape(-1).to(dev)
+    batch = DeviceBatch(pack_lengths([SEQ_LEN] * BATCH), dev)
+
+    gather = (world > 1) and not args.no_gather
+    side = torch.cuda.Stream() if gather else None
+    gathered = torch.empty((world * n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
+    send = torch.empty((n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
+    gather_note = "off"
+
+    def step():
+        nonlocal gather, gather_note
+        logits, post, _ = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=True)
+        if gather:
+            try:
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    send.copy_(post)  # fp32 -> bf16 wire format
+                    dist.all_gather_into_tensor(gathered, send)
+                post.record_stream(side)
+                gather_note = "all_gather bf16 embeddings, side stream"
+            except Exception as e:  # keep the measurement alive; say so in the JSON
+                gather = False
+                gather_note = f"failed: {type(e).__name__}: {e}"[:200]
+        return logits
+
+    def sync_all():
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * n_tok * args.steps / elapsed
+        fpr = flop_per_residue()
+        kt = time_dominant_kernel(model, n_tok)
+        kflop = 2.0 * n_tok * (2 * FFN_H) * D_MODEL
+        achieved = kflop / kt / 1e12
+        line = {
+            "metric": "residues/sec ESM C 600M fwd at L=512", "value": value, "unit": "residues/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "ESM C 600M-shaped (d1152, 18 heads, 36 layers, random init) forward incl. "
+                                   "sequence head, 64 x L=512 residues per GPU (BASELINE.json configs[1])",
+                       "global_batch": world * BATCH, "seq_len": SEQ_LEN, "parallelism": f"dp{world}",
+                       "result_gather": gather_note},
+            "mfma_frac_end_to_end": value / world * fpr / (PEAK_TFLOPS * 1e12),
+            "flop_per_residue": fpr,
+            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
+                         "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
+                         "traffic": None, "launch_ms": kt * 1e3},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(weights)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

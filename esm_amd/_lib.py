@@ -82,6 +82,9 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise EsmkError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                             "(or `make -C esm_amd/csrc`). There is no non-HIP fallback.")
+        # torch ships its own libamdhip64 (same soname): load it FIRST so that libesmk.so binds to the one HIP
+        # runtime torch's allocator and streams live in; the other order leaves two runtimes in the process.
+        import torch  # noqa: F401
         l = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)
