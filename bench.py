@@ -40,31 +40,20 @@ def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
     return layers * (8 * d * d + 6 * d * h + 4 * L * d) + 2 * d * d + 2 * d * 64
 
 
-def time_dominant_kernel(model, n_tokens, iters=20):
-    """Mean launch duration (s) of the FFN1 (SwiGLU) GEMM via HIP events on the current stream."""
-    from esm_amd import _lib as L
-    lib = L.lib()
+def time_dominant_kernel(model, tokens, batch, steps=3):
+    """Mean in-situ launch duration (s) of the FFN up-projection (SwiGLU) GEMM: HIP events recorded on the
+    launch stream around that kernel in every layer of `steps` extra forwards (same launches rocprof sees)."""
     eng = model.transformer.engine()
-    a = (torch.randn(n_tokens, D_MODEL, device="cuda") * 1.0).bfloat16()
-    out = torch.empty(n_tokens, FFN_H, dtype=torch.bfloat16, device="cuda")
-    w = eng._layers[N_LAYERS // 2].w_ffn1
-    st = torch.cuda.current_stream().cuda_stream
-
-    def run():
-        L.check(lib.esmk_gemm(a.data_ptr(), D_MODEL, w, n_tokens, 2 * FFN_H, D_MODEL, L.EPI_SWIGLU, None, 1.0,
-                              out.data_ptr(), st))
-    for _ in range(3):
-        run()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        run()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / iters
+    eng.enable_probes(True)
+    ts = []
+    for _ in range(steps):
+        model.forward_packed(tokens, batch, want_hiddens=False, want_logits=True)
+        ts += eng.probe_times_ms()
+    eng.enable_probes(False)
+    return sum(ts) / len(ts) * 1e-3
 
 
-def cpu_baseline(weights, n_seqs=4):
+def cpu_baseline(weights, n_seqs=16):
     """Oracle (port of the reference's fp32 path) on a bounded sample: n_seqs x 512 residues, all 36 layers."""
     from esm_amd import synth
     from oracle import trunk_ref  # checker / baseline only
@@ -163,7 +152,7 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * n_tok * args.steps / elapsed
         fpr = flop_per_residue()
-        kt = time_dominant_kernel(model, n_tok)
+        kt = time_dominant_kernel(model, tokens, batch)
         kflop = 2.0 * n_tok * (2 * FFN_H) * D_MODEL
         achieved = kflop / kt / 1e12
         line = {

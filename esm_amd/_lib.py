@@ -32,7 +32,8 @@ class EsmkLayer(C.Structure):
 class EsmkTrunk(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("n_layers", C.c_int), ("ffn_hidden", C.c_int),
                 ("v_heads", C.c_int), ("residual_scale", C.c_float), ("layers", C.POINTER(EsmkLayer)),
-                ("final_norm_g", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int)]
+                ("final_norm_g", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
+                ("probe_start", C.POINTER(vp)), ("probe_stop", C.POINTER(vp))]
 
 
 class EsmkBatch(C.Structure):
@@ -65,6 +66,10 @@ SIGNATURES = {
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
     "esmk_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_head_forward": (C.c_int, [C.POINTER(EsmkHead), vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "esmk_event_create": (C.c_int, [C.POINTER(vp)]),
+    "esmk_event_destroy": (C.c_int, [vp]),
+    "esmk_event_record": (C.c_int, [vp, vp]),
+    "esmk_event_elapsed_ms": (C.c_int, [vp, vp, C.POINTER(C.c_float)]),
 }
 
 

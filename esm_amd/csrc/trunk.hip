@@ -125,7 +125,9 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
         }
         // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
         TRY(esmk_layernorm(x, ESMK_F32, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
+        if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
         TRY(esmk_gemm(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, stream));
+        if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
         TRY(esmk_gemm(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
         if (hiddens) {
             if (hipMemcpyAsync(hiddens + (size_t)i * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
@@ -180,5 +182,28 @@ int esmk_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s) {
     const size_t n4 = n / 4;  // callers pass multiples of 4 (d % 64 == 0)
     hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, in, (__bf16*)out, n4);
     ESMK_CHECK_LAUNCH("esmk_cast_f32_bf16");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_event_create(void** ev) {
+    if (!ev) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_event_create: null pointer");
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_event_create: hipEventCreate failed");
+    *ev = (void*)e;
+    return ESMK_OK;
+}
+extern "C" int esmk_event_destroy(void* ev) {
+    if (ev && hipEventDestroy((hipEvent_t)ev) != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_event_destroy failed");
+    return ESMK_OK;
+}
+extern "C" int esmk_event_record(void* ev, esmk_stream_t stream) {
+    if (!ev) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_event_record: null event");
+    if (hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_event_record failed");
+    return ESMK_OK;
+}
+extern "C" int esmk_event_elapsed_ms(void* a, void* b, float* ms) {
+    if (!a || !b || !ms) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_event_elapsed_ms: null pointer");
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_event_elapsed_ms: sync failed");
+    if (hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) != hipSuccess) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_event_elapsed_ms failed");
     return ESMK_OK;
 }

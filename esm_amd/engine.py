@@ -131,6 +131,32 @@ class TrunkEngine:
         self._cos, self._sin = cos.to(self.device), sin.to(self.device)
         self._desc.rope_cos, self._desc.rope_sin, self._desc.rope_len = L.ptr(self._cos), L.ptr(self._sin), n_pos
 
+    def enable_probes(self, on: bool = True):
+        """Record HIP events around every layer's FFN up-projection GEMM (the dominant kernel)."""
+        if on and not getattr(self, "_probe_ev", None):
+            n = self.n_layers
+            self._probe_ev = ((L.vp * n)(), (L.vp * n)())
+            for arr in self._probe_ev:
+                for i in range(n):
+                    e = L.vp()
+                    L.check(self.lib.esmk_event_create(C.byref(e)), "esmk_event_create")
+                    arr[i] = e.value
+        if on:
+            self._desc.probe_start = C.cast(self._probe_ev[0], C.POINTER(L.vp))
+            self._desc.probe_stop = C.cast(self._probe_ev[1], C.POINTER(L.vp))
+        else:
+            self._desc.probe_start = None
+            self._desc.probe_stop = None
+
+    def probe_times_ms(self):
+        """Per-layer duration of the probed kernel in the LAST forward (synchronises)."""
+        out = []
+        for i in range(self.n_layers):
+            ms = C.c_float()
+            L.check(self.lib.esmk_event_elapsed_ms(self._probe_ev[0][i], self._probe_ev[1][i], C.byref(ms)))
+            out.append(ms.value)
+        return out
+
     def workspace(self, n_tokens: int) -> torch.Tensor:
         need = self.lib.esmk_trunk_workspace_bytes(C.byref(self._desc), n_tokens)
         if self._ws is None or self._ws.numel() < need:

@@ -61,7 +61,7 @@ int esmk_pack_weight(const float* w_f32, void* packed, int N, int K, int mode, e
  * Replaces: nn.LayerNorm in layernorm_qkv[0], ffn[0], transformer.norm, RegressionHead[2],
  * geom_attn.s_norm (reference esm/layers/attention.py:26-28, blocks.py:31,
  * transformer_stack.py:62,94, regression_head.py:20, geom_attention.py:38,65).
- * x [M, d] (x_dtype), y [M, ldy] (y_dtype) written in columns [0, d); beta may be NULL.
+ * x [M, d] (x_dtype) -> y [M, d] (y_dtype); beta may be NULL.
  * ------------------------------------------------------------------------------------------ */
 int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                    int M, int d, float eps, esmk_stream_t stream);
@@ -197,6 +197,9 @@ typedef struct {
     const esmk_layer* layers;      /* HOST array of n_layers */
     const float* final_norm_g;     /* transformer.norm.weight */
     const float* rope_cos; const float* rope_sin; int rope_len;
+    /* optional profiling probes (NULL = off): arrays of n_layers events (esmk_event_create) recorded on `stream`
+     * immediately before / after each layer's FFN up-projection GEMM, the dominant kernel of the forward. */
+    void* const* probe_start; void* const* probe_stop;
 } esmk_trunk;
 
 typedef struct {
@@ -228,6 +231,15 @@ typedef struct {
 size_t esmk_head_workspace_bytes(int n_tokens, int d_model);
 int esmk_head_forward(const esmk_head* h, const float* x_norm, float* logits, int M, int d, void* workspace,
                       size_t workspace_bytes, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Timing helpers (thin wrappers over hipEvent*, so that a harness without HIP headers can time kernels on
+ * the stream they are launched on).  No counterpart in the reference.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_event_create(void** event);
+int esmk_event_destroy(void* event);
+int esmk_event_record(void* event, esmk_stream_t stream);
+int esmk_event_elapsed_ms(void* start, void* stop, float* ms); /* synchronises on `stop` */
 
 #ifdef __cplusplus
 }

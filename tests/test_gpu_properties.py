@@ -1,0 +1,87 @@
+"""Size-independent properties of the HIP path at realistic widths (no oracle needed):
+padding invariance, bin-packing invariance, run-to-run determinism, DP runner == direct forward."""
+import pytest
+import torch
+
+from esm_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    from esm_amd.esmc import ESMC
+    d, H, NL = 1152, 18, 4
+    m = ESMC(d, H, NL)
+    m.load_state_dict(synth.esmc_weights(d, NL, seed=77))
+    return m.cuda()
+
+
+def test_padded_batch_equals_single_sequences(model):
+    lens = [512, 301, 64, 130]
+    tok = synth.synth_tokens(lens, seed=9).cuda()
+    out = model(tok)
+    for i, n in enumerate(lens):
+        single = model(tok[i:i + 1, :n])
+        # same kernels, same per-row arithmetic: only the tile a row lands in differs -> tight tolerance
+        assert (out.embeddings[i, :n] - single.embeddings[0]).abs().max().item() <= 2e-2
+        cos = torch.nn.functional.cosine_similarity(out.embeddings[i, :n], single.embeddings[0], dim=-1).min().item()
+        assert cos >= 0.9999
+        assert (out.sequence_logits[i, :n] - single.sequence_logits[0]).abs().max().item() <= 2e-2
+        assert out.embeddings[i, n:].abs().max().item() == 0.0 if n < max(lens) else True
+
+
+def test_binpacked_sequence_id_equals_separate(model):
+    lens = [200, 180, 120]
+    toks = [synth.synth_tokens([n], seed=40 + i)[0] for i, n in enumerate(lens)]
+    row = torch.cat(toks)[None].cuda()
+    sid = torch.cat([torch.full((n,), i, dtype=torch.int64) for i, n in enumerate(lens)])[None].cuda()
+    packed = model(row, sequence_id=sid)
+    off = 0
+    for i, n in enumerate(lens):
+        single = model(toks[i][None].cuda())
+        a, b = packed.embeddings[0, off:off + n], single.embeddings[0]
+        # rotary position = column in the packed row vs restart at 0: RoPE is relative -> equal to bf16 rounding
+        cos = torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
+        assert cos >= 0.9995, cos
+        off += n
+
+
+def test_deterministic(model):
+    tok = synth.synth_tokens([512] * 8, seed=5).cuda()
+    a = model(tok)
+    b = model(tok)
+    assert torch.equal(a.embeddings, b.embeddings)
+    assert torch.equal(a.sequence_logits, b.sequence_logits)
+    assert torch.equal(a.hidden_states, b.hidden_states)
+
+
+def test_outputs_finite_at_full_c2_shape(model):
+    tok = synth.synth_tokens([512] * 64, seed=1).cuda()
+    out = model(tok, return_hidden_states=False)
+    assert out.hidden_states is None
+    assert torch.isfinite(out.embeddings).all() and torch.isfinite(out.sequence_logits).all()
+    # LayerNorm output: per-row mean ~ 0 and variance ~ |gamma|^2-weighted 1 -> rows must not be degenerate
+    assert out.embeddings.std(dim=-1).min().item() > 0.1
+
+
+def test_dp_runner_single_process_equals_forward(model):
+    from esm_amd.dp import esmc_compute_fn, run_data_parallel
+    lens = [64, 700, 129, 300, 33, 512]
+    seqs = [synth.synth_tokens([n], seed=60 + i)[0] for i, n in enumerate(lens)]
+    res = run_data_parallel(seqs, esmc_compute_fn(model), 1152, d=1152, h=3072, token_budget=1024,
+                            device=torch.device("cuda"), wire_dtype=torch.float32)
+    for s, r in zip(seqs, res):
+        direct = model(s[None].cuda(), return_hidden_states=False).embeddings[0]
+        cos = torch.nn.functional.cosine_similarity(r, direct, dim=-1).min().item()
+        assert cos >= 0.9999, cos
+
+
+def test_long_sequence_4096(model):
+    """Config-5 style stress: one 4096-residue segment (rotary table growth, 64 KV tiles per query block)."""
+    tok = synth.synth_tokens([4096], seed=3).cuda()
+    out = model(tok, return_hidden_states=False)
+    assert torch.isfinite(out.embeddings).all()
+    # the first 64 residues must differ from a truncated run (they attend to the whole sequence)
+    short = model(tok[:, :64], return_hidden_states=False)
+    assert (out.embeddings[0, :64] - short.embeddings[0]).abs().max().item() > 1e-3
