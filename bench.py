@@ -165,7 +165,7 @@ def main():
                        "result_gather": gather_note},
             "mfma_frac_end_to_end": value / world * fpr / (PEAK_TFLOPS * 1e12),
             "flop_per_residue": fpr,
-            "roofline": {"bound": "mfma", "kernel": "gemm_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
                          "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": None, "launch_ms": kt * 1e3},
         }

@@ -11,7 +11,10 @@
 // chunk index is XOR-swizzled with (row>>1)&7 - applied on the per-lane SOURCE address (the DMA writes
 // LDS linearly) and on the ds_read_b128 address - which makes the 16-lane ds_read_b128 groups
 // conflict-free.
+#include <stdlib.h>
+
 #include "common.hpp"
+#include "gemm_epi.hpp"
 
 namespace {
 
@@ -24,8 +27,6 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
 
 template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ A, int lda,
@@ -110,62 +111,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
         const int t = t0 + wc * 64 + j * 16 + (lane & 15);
         if (t >= M) continue;
         if constexpr (EPI == ESMK_EPI_SWIGLU) {
-            const int hw = N >> 1;  // output width
-            __bf16* o = (__bf16*)out + (size_t)t * hw;
 #pragma unroll
-            for (int i = 0; i < 4; i += 2) {
-                const int c = ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4;
-                if (c < hw) {
-                    const f32x4 g = acc[i][j], u = acc[i + 1][j];
-                    u32x2 v;
-                    v.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
-                    v.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
-                    *(u32x2*)(o + c) = v;
-                }
-            }
+            for (int i = 0; i < 4; i += 2)
+                epi_swiglu4(acc[i][j], acc[i + 1][j], t, ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4, N >> 1, out);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int c = c0 + wr * 64 + i * 16 + q4;
-                if (c >= N) continue;
-                f32x4 v = acc[i][j];
-                const bool full = ((N & 3) == 0);  // then c+3 < N as well
-                if constexpr (EPI == ESMK_EPI_RESIDUAL) {
-                    float* o = (float*)out + (size_t)t * N + c;
-                    f32x4 x = *(f32x4*)o;
-                    x += v * alpha;
-                    *(f32x4*)o = x;
-                } else if constexpr (EPI == ESMK_EPI_BF16 || EPI == ESMK_EPI_BIAS_GELU) {
-                    __bf16* o = (__bf16*)out + (size_t)t * N + c;
-                    if constexpr (EPI == ESMK_EPI_BIAS_GELU) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r] + (c + r < N ? bias[c + r] : 0.f));
-                    }
-                    if (full) {
-                        u32x2 pk;
-                        pk.x = pack_bf16x2(v[0], v[1]);
-                        pk.y = pack_bf16x2(v[2], v[3]);
-                        *(u32x2*)o = pk;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (c + r < N) o[r] = (__bf16)v[r];
-                    }
-                } else {  // ESMK_EPI_F32
-                    float* o = (float*)out + (size_t)t * N + c;
-                    if (bias) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += (c + r < N ? bias[c + r] : 0.f);
-                    }
-                    if (full) {
-                        *(f32x4*)o = v;
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (c + r < N) o[r] = v[r];
-                    }
-                }
-            }
+            for (int i = 0; i < 4; ++i) epi_store4<EPI>(acc[i][j], t, c0 + wr * 64 + i * 16 + q4, N, bias, alpha, out);
         }
     }
 }
@@ -221,9 +172,22 @@ int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
 
 }  // namespace
 
+int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                 float alpha, void* out, hipStream_t s);
+
+// 0 = auto, 128 / 256 = force a tile family (ESMK_GEMM_TILE environment variable; for experiments and tests)
+static int gemm_tile_override() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("ESMK_GEMM_TILE");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
+}
+
 extern "C" size_t esmk_packed_weight_bytes(int N, int K) {
     if (N <= 0 || K <= 0) return 0;
-    return (size_t)round_up(N, BW) * round_up(K, BK) * 2;
+    return (size_t)round_up(N, 256) * round_up(K, BK) * 2;
 }
 
 extern "C" int esmk_pack_weight(const float* w, void* packed, int N, int K, int mode, esmk_stream_t stream) {
@@ -231,7 +195,7 @@ extern "C" int esmk_pack_weight(const float* w, void* packed, int N, int K, int 
     if (mode != ESMK_PACK_PLAIN && mode != ESMK_PACK_SWIGLU) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_pack_weight: bad mode");
     if (mode == ESMK_PACK_SWIGLU && (N % 32) != 0)
         ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_pack_weight: SwiGLU packing needs N %% 32 == 0 (got %d)", N);
-    const int Npad = round_up(N, BW), Kpad = round_up(K, BK);
+    const int Npad = round_up(N, 256), Kpad = round_up(K, BK);
     const size_t total = (size_t)Npad * (Kpad / 8);
     hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
                        (__bf16*)packed, N, K, Npad, Kpad, mode);
@@ -248,6 +212,15 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: lda=%d must be >= round_up(K,64)=%d and a multiple of 8", lda,
                   round_up(K, BK));
     hipStream_t s = (hipStream_t)stream;
+    if (epilogue == ESMK_EPI_SWIGLU && (N % 32)) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm: SwiGLU epilogue needs N %% 32 == 0");
+    if (epilogue == ESMK_EPI_RESIDUAL && (N % 4)) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm: residual epilogue needs N %% 4 == 0");
+    if (epilogue == ESMK_EPI_BIAS_GELU && !bias) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bias+gelu epilogue needs a bias");
+    {
+        // large problems: 256x256 ping-pong kernel; small / skinny ones: 128x128 (more, smaller workgroups)
+        const int ov = gemm_tile_override();
+        const bool big = (long long)M * N >= 256LL * 256 * 256 && N >= 256 && M >= 256;
+        if (ov == 256 || (ov == 0 && big)) return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s);
+    }
     switch (epilogue) {
         case ESMK_EPI_BF16: return launch_gemm<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s);
         case ESMK_EPI_F32: return launch_gemm<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s);
