@@ -53,6 +53,7 @@ SIGNATURES = {
     "esmk_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_layernorm": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "esmk_add_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "esmk_gemm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),

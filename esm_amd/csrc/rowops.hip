@@ -8,10 +8,12 @@ namespace {
 // --------------------------------------------------------------------------------------------------
 constexpr int LN_MAX_VEC = 16;  // 16 float4 per lane -> d <= 4096
 
-template <typename TIN, typename TOUT>
+// ADD: x (f32, in/out) += delta (bf16) before normalising; the updated row is written back to x.
+template <typename TIN, typename TOUT, bool ADD = false>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOUT* __restrict__ y, int M,
-                                                        int d, int ldy, float eps) {
+                                                        int d, int ldy, float eps,
+                                                        const __bf16* __restrict__ delta = nullptr) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -28,6 +30,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
                 const u32x2 p = *(const u32x2*)((const __bf16*)x + (size_t)row * d + c * 4);
                 v[i] = f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u),
                              __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
+            }
+            if constexpr (ADD) {
+                const u32x2 p = *(const u32x2*)(delta + (size_t)row * d + c * 4);
+                v[i] += f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u),
+                              __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
+                *(f32x4*)((float*)x + (size_t)row * d + c * 4) = v[i];
             }
             sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
         }
@@ -256,6 +264,25 @@ extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, co
     else
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_layernorm: bad dtype");
     ESMK_CHECK_LAUNCH("esmk_layernorm");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamma, const float* beta, void* y,
+                                  int y_dtype, int M, int d, float eps, esmk_stream_t stream) {
+    if (!delta) return esmk_layernorm(x, ESMK_F32, gamma, beta, y, y_dtype, M, d, eps, stream);
+    if (!x || !gamma || !y) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add_layernorm: null pointer");
+    if (M < 0 || d <= 0 || (d & 3) || d > LN_MAX_VEC * 256)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_add_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
+    if (M == 0) return ESMK_OK;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((M + 3) / 4), block(256);
+    if (y_dtype == ESMK_BF16)
+        hipLaunchKernelGGL((layernorm_kernel<float, __bf16, true>), grid, block, 0, s, (const float*)x, gamma, beta, (__bf16*)y, M, d, d, eps, (const __bf16*)delta);
+    else if (y_dtype == ESMK_F32)
+        hipLaunchKernelGGL((layernorm_kernel<float, float, true>), grid, block, 0, s, (const float*)x, gamma, beta, (float*)y, M, d, d, eps, (const __bf16*)delta);
+    else
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add_layernorm: bad dtype");
+    ESMK_CHECK_LAUNCH("esmk_add_layernorm");
     return ESMK_OK;
 }
 

@@ -26,7 +26,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TrunkWs {
-    size_t xn, qkv, ctx, hbuf, gproj, gout, gscratch, total;
+    size_t xn, qkv, ctx, hbuf, dbuf, gproj, gout, gscratch, total;
 };
 
 TrunkWs trunk_layout(const esmk_trunk* t, int M) {
@@ -37,6 +37,7 @@ TrunkWs trunk_layout(const esmk_trunk* t, int M) {
     w.qkv = off;  off += align256((size_t)M * 3 * d * 2);
     w.ctx = off;  off += align256((size_t)M * d * 2);
     w.hbuf = off; off += align256((size_t)M * h * 2);
+    w.dbuf = off; off += align256((size_t)M * d * 2);
     bool geom = false;
     for (int i = 0; i < t->n_layers; ++i) geom = geom || (t->layers[i].geom_ln_g != nullptr);
     if (geom) {
@@ -97,16 +98,26 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
     const float q_scale = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
     hipStream_t s = (hipStream_t)stream;
 
+    // Residual updates travel as bf16 deltas (already scaled by 1/s in the producing GEMM's epilogue) and are
+    // folded into the fp32 stream by the NEXT LayerNorm pass (esmk_add_layernorm): x is read and written once
+    // per sub-block instead of twice, and every big GEMM ends in a coalesced bf16 store.
+    void* dbuf = ws + w.dbuf;
+    const void* pending = nullptr;  // delta not yet added to x
     for (int i = 0; i < t->n_layers; ++i) {
         const esmk_layer& L = t->layers[i];
         if (!L.ln1_g || !L.ln1_b || !L.w_qkv || !L.qln_g || !L.kln_g || !L.w_o || !L.ln2_g || !L.ln2_b || !L.w_ffn1 || !L.w_ffn2)
             ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
         // --- x += MHA(x) / s  (attention.py:48-82, blocks.py:146-148)
-        TRY(esmk_layernorm(x, ESMK_F32, L.ln1_g, L.ln1_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(esmk_add_layernorm(x, pending, L.ln1_g, L.ln1_b, xn, ESMK_BF16, M, d, eps, stream));
+        if (hiddens && i > 0) {  // x now holds block i-1's output
+            if (hipMemcpyAsync(hiddens + (size_t)(i - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
+        }
         TRY(esmk_gemm(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, stream));
         TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
         TRY(esmk_attn_varlen(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, stream));
-        TRY(esmk_gemm(ctx, d, L.w_o, M, d, d, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
+        TRY(esmk_gemm(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+        pending = dbuf;
         // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)
         if (L.geom_ln_g) {
             const int vh = t->v_heads;
@@ -117,24 +128,28 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
             float* gproj = (float*)(ws + w.gproj);
             void* gout = ws + w.gout;
             const int ldg = round_up(3 * vh, 64);
-            TRY(esmk_layernorm(x, ESMK_F32, L.geom_ln_g, nullptr, xn, ESMK_BF16, M, d, eps, stream));
+            TRY(esmk_add_layernorm(x, pending, L.geom_ln_g, nullptr, xn, ESMK_BF16, M, d, eps, stream));
             TRY(esmk_gemm(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, stream));
             TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
                                b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
-            TRY(esmk_gemm(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
+            TRY(esmk_gemm(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+            pending = dbuf;
         }
         // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
-        TRY(esmk_layernorm(x, ESMK_F32, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(esmk_add_layernorm(x, pending, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
         if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
         TRY(esmk_gemm(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, stream));
         if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
-        TRY(esmk_gemm(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_RESIDUAL, nullptr, inv_s, x, stream));
-        if (hiddens) {
-            if (hipMemcpyAsync(hiddens + (size_t)i * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-                ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
-        }
+        TRY(esmk_gemm(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+        pending = dbuf;
     }
-    if (post_norm) TRY(esmk_layernorm(x, ESMK_F32, t->final_norm_g, nullptr, post_norm, ESMK_F32, M, d, eps, stream));
+    // final: fold the last delta into x (pre-norm output) and normalise (transformer_stack.py:94)
+    void* post = post_norm ? (void*)post_norm : xn;
+    TRY(esmk_add_layernorm(x, pending, t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16, M, d, eps, stream));
+    if (hiddens) {
+        if (hipMemcpyAsync(hiddens + (size_t)(t->n_layers - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
+    }
     return ESMK_OK;
 }
 

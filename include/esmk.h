@@ -14,7 +14,7 @@
  *   - the caller owns every buffer; nothing here allocates device memory or synchronises the device.
  *   - work is enqueued on `stream` and is ordered with other work on that stream.
  *   - activations: packed tokens, row-major [n_tokens, width]; no row padding is required.
- *   - "packed weight": bf16 [round_up(N,128), round_up(K,64)] produced by esmk_pack_weight.
+ *   - "packed weight": bf16 [round_up(N,256), round_up(K,64)] produced by esmk_pack_weight.
  */
 #ifndef ESMK_H
 #define ESMK_H
@@ -46,7 +46,7 @@ const char* esmk_last_error(void);
 /* ------------------------------------------------------------------------------------------
  * Weight packing (once per model).
  * Replaces: nothing at run time; consumes the reference state_dict tensors (fp32 [N,K] row-major,
- * SURVEY.md 8b) and lays them out for the MFMA GEMM: bf16, rows padded to 128, K padded to 64.
+ * SURVEY.md 8b) and lays them out for the MFMA GEMM: bf16, rows padded to 256, K padded to 64.
  * mode ESMK_PACK_SWIGLU interleaves the gate rows [0,N/2) and up rows [N/2,N) of ffn.1.weight
  * (reference esm/layers/blocks.py:26-27) in groups of 16 so one MFMA tile pair owns gate+up of the
  * same channels.
@@ -66,11 +66,18 @@ int esmk_pack_weight(const float* w_f32, void* packed, int N, int K, int mode, e
 int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                    int M, int d, float eps, esmk_stream_t stream);
 
+/* Fused residual update + LayerNorm:  x (f32 [M,d], in/out) += delta (bf16 [M,d]);  y = LN(x).
+ * Replaces the residual add of UnifiedTransformerBlock (reference esm/layers/blocks.py:147-155; the 1/s scale is
+ * applied by the producing GEMM's epilogue) fused with the LayerNorm that consumes the updated stream
+ * (attention.py:26, blocks.py:31, geom_attention.py:65, transformer_stack.py:94).  delta == NULL: plain LN. */
+int esmk_add_layernorm(float* x, const void* delta_bf16, const float* gamma, const float* beta, void* y,
+                       int y_dtype, int M, int d, float eps, esmk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * GEMM  out = epilogue(A[M,K] . W[N,K]^T)  on bf16 MFMA with fp32 accumulation.
  * Replaces: every nn.Linear on the path (reference attention.py:27,29,82; blocks.py:32-37;
  * geom_attention.py:43,45; regression_head.py:18,21) with the op that follows it fused:
- *   ESMK_EPI_BF16       out bf16 [M,N]            = acc
+ *   ESMK_EPI_BF16       out bf16 [M,N]            = alpha * acc            (alpha = 1/s makes it a residual delta)
  *   ESMK_EPI_F32        out f32  [M,N]            = acc (+ bias if bias != NULL)
  *   ESMK_EPI_SWIGLU     out bf16 [M,N/2]          = silu(gate) * up       (blocks.py:26-27; W packed SWIGLU)
  *   ESMK_EPI_RESIDUAL   out f32  [M,N] (in/out)   += alpha * acc           (blocks.py:147-155, alpha = 1/s)

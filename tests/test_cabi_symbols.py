@@ -31,8 +31,8 @@ def test_ctypes_table_matches_header():
 def test_version_and_host_only_calls():
     lib = _lib.lib()
     assert lib.esmk_version() == 100
-    assert lib.esmk_packed_weight_bytes(3456, 1152) == 3456 * 1152 * 2
-    assert lib.esmk_packed_weight_bytes(11, 24) == 128 * 64 * 2
+    assert lib.esmk_packed_weight_bytes(3456, 1152) == 3584 * 1152 * 2  # rows padded to 256
+    assert lib.esmk_packed_weight_bytes(11, 24) == 256 * 64 * 2
     assert lib.esmk_head_workspace_bytes(100, 128) >= 3 * 100 * 128 * 2
     # host-side planner: pure C, no device
     import numpy as np
