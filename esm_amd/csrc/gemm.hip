@@ -174,6 +174,8 @@ int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                  float alpha, void* out, hipStream_t s);
+int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
+                  hipStream_t s);
 
 // 0 = auto, 128 / 256 = force a tile family (ESMK_GEMM_TILE environment variable; for experiments and tests)
 static int gemm_tile_override() {
@@ -219,7 +221,18 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
         // large problems: 256x256 ping-pong kernel; small / skinny ones: 128x128 (more, smaller workgroups)
         const int ov = gemm_tile_override();
         const bool big = (long long)M * N >= 256LL * 256 * 256 && N >= 256 && M >= 256;
-        if (ov == 256 || (ov == 0 && big)) return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s);
+        if (ov == 256 || (ov == 0 && big)) {
+            // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
+            // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call
+            // so that tests can exercise both.
+            const char* e = getenv("ESMK_GEMM_PERSIST");
+            const int persist = e ? atoi(e) : 0;
+            if (persist && (epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU)) {
+                const int rc = esmk_gemm256p(A, lda, W, M, N, K, epilogue, alpha, out, s);
+                if (rc <= 0) return rc;  // 1 = shape not eligible for the persistent kernel
+            }
+            return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s);
+        }
     }
     switch (epilogue) {
         case ESMK_EPI_BF16: return launch_gemm<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s);

@@ -39,12 +39,16 @@ __device__ unsigned long long g_stamps[8 * 64];
 #define STAMP(i)
 #endif
 
+#ifdef ESMK_NOBAR  /* timing experiment only: results are wrong */
+#define SEG_BARRIER() __builtin_amdgcn_sched_barrier(0)
+#else
 #define SEG_BARRIER()                        \
     do {                                     \
         __builtin_amdgcn_sched_barrier(0);   \
         __builtin_amdgcn_s_barrier();        \
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
+#endif
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ A, int lda,
@@ -123,7 +127,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
     auto issue_piece = [&](int u, int i, int kt) {
         if (dbg & 1) return;
         char* dst = smem + (kt & 1) * KBUF + u * UNIT + dma_dst + i * 1024;
+#ifdef ESMK_SAMEDMA  /* timing experiment only: every tile streams the same 64 KiB */
+        const char* base = ((u == 0 || u == 3) ? (const char*)W : (const char*)A);
+#else
         const char* base = ((u == 0 || u == 3) ? wbase : abase) + (size_t)kt * (BK * 2);
+#endif
         __builtin_amdgcn_global_load_lds(GLB_PTR(base + soff[u][i]), LDS_PTR(dst), 16, 0, 0);
     };
     auto read_a_kk = [&](const char* unit, int kk) {

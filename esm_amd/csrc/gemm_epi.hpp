@@ -3,7 +3,10 @@
 #include "common.hpp"
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
-__device__ __forceinline__ float silu(float x) { return x / (1.0f + __expf(-x)); }
+// silu(x) = x * sigmoid(x) on the hardware exp2 / rcp units (about 1 ulp each; the result is rounded to bf16)
+__device__ __forceinline__ float silu(float x) {
+    return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 
 // SwiGLU: g/u = gate/up accumulators of the same 4 channels; c = OUTPUT channel, hw = output width.
 __device__ __forceinline__ void epi_swiglu4(const f32x4 g, const f32x4 u, int t, int c, int hw, void* out) {

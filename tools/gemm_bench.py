@@ -6,6 +6,8 @@ import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from esm_amd import _lib as L
+if os.environ.get("ESMK_LIB"):
+    L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), os.environ["ESMK_LIB"])
 from esm_amd import engine
 
 SHAPES = [("ffn1_swiglu", 32768, 6144, 1152, L.EPI_SWIGLU), ("qkv_bf16", 32768, 3456, 1152, L.EPI_BF16),
