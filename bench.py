@@ -33,6 +33,9 @@ import torch  # noqa: E402
 D_MODEL, N_HEADS, N_LAYERS, FFN_H = 1152, 18, 36, 3072
 BATCH, SEQ_LEN = 64, 512
 PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
+# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction for
+# 16-B/lane streams] + WRITE_SIZE, KiB -> bytes): profiles/r01_pmc_gemm_ffn1.json.  Algorithmic bytes: 291 MB.
+DOMINANT_KERNEL_HBM_BYTES = 880_983_979
 
 
 def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
@@ -167,7 +170,8 @@ def main():
             "flop_per_residue": fpr,
             "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
                          "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": None, "launch_ms": kt * 1e3},
+                         "traffic": DOMINANT_KERNEL_HBM_BYTES, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_gemm_ffn1.json)",
+                         "launch_ms": kt * 1e3},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)

@@ -72,11 +72,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ 
 
 // --------------------------------------------------------------------------------------------------
 // QK-LayerNorm (over the full d_model width, bias-free) + NeoX rotary per 64-wide head, in place.
-// One 128-thread block per token.  A "unit" is (q|k, head, 8-column chunk c in 0..3) and covers columns
-// [8c, 8c+8) and their rotary partners [32+8c, 32+8c+8) of that head: 8*H units per token.
+// One WAVE per token (4 tokens per 256-thread block): the q and k rows live in registers, statistics are
+// wave shuffles - no LDS, no block barrier.  A "unit" is (q|k, head, 8-column chunk c in 0..3) and covers
+// columns [8c, 8c+8) and their rotary partners [32+8c, 32+8c+8) of that head: 8*H units per token.
 // --------------------------------------------------------------------------------------------------
-constexpr int QK_THREADS = 128;
-constexpr int QK_MAX_UNITS = 4;  // per thread -> 8*H <= 512 -> H <= 64
+constexpr int QK_MAX_UNITS = 6;  // per lane -> 8*H <= 384 -> H <= 48
 
 __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 #pragma unroll
@@ -86,30 +86,24 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
     }
 }
 
-__device__ __forceinline__ float block_sum_128(float v, float* red) {
-    v = wave_sum(v);
-    __syncthreads();  // protect red from the previous use
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return red[0] + red[1];
-}
-
-__global__ __launch_bounds__(QK_THREADS) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
-                                                             const float* __restrict__ gk,
-                                                             const int* __restrict__ positions,
-                                                             const float* __restrict__ rcos,
-                                                             const float* __restrict__ rsin, int rope_len, int d,
-                                                             int H, float q_scale, float eps) {
-    __shared__ float red[2];
-    const int tok = blockIdx.x;
+template <int NU>  // units per lane (compile-time so the row stays in registers)
+__global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
+                                                      const float* __restrict__ gk,
+                                                      const int* __restrict__ positions,
+                                                      const float* __restrict__ rcos,
+                                                      const float* __restrict__ rsin, int rope_len, int M, int d,
+                                                      int H, float q_scale, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tok >= M) return;
     __bf16* row = qkv + (size_t)tok * 3 * d;
     const int units_half = 4 * H;  // units for q; same count for k
     const int nunits = 2 * units_half;
-    float lo[QK_MAX_UNITS][8], hi[QK_MAX_UNITS][8];
+    float lo[NU][8], hi[NU][8];
     float sq_ = 0.f, sk_ = 0.f;
 #pragma unroll
-    for (int u = 0; u < QK_MAX_UNITS; ++u) {
-        const int unit = threadIdx.x + u * QK_THREADS;
+    for (int u = 0; u < NU; ++u) {
+        const int unit = lane + u * 64;
         if (unit < nunits) {
             const int isk = unit >= units_half;
             const int uu = unit - isk * units_half;
@@ -122,12 +116,13 @@ __global__ __launch_bounds__(QK_THREADS) void qk_prep_kernel(__bf16* __restrict_
             if (isk) sk_ += s; else sq_ += s;
         }
     }
-    const float mean_q = block_sum_128(sq_, red) / (float)d;
-    const float mean_k = block_sum_128(sk_, red) / (float)d;
+    const float inv_d = 1.0f / (float)d;
+    const float mean_q = wave_sum(sq_) * inv_d;
+    const float mean_k = wave_sum(sk_) * inv_d;
     sq_ = 0.f; sk_ = 0.f;
 #pragma unroll
-    for (int u = 0; u < QK_MAX_UNITS; ++u) {
-        const int unit = threadIdx.x + u * QK_THREADS;
+    for (int u = 0; u < NU; ++u) {
+        const int unit = lane + u * 64;
         if (unit < nunits) {
             const int isk = unit >= units_half;
             const float m = isk ? mean_k : mean_q;
@@ -141,15 +136,15 @@ __global__ __launch_bounds__(QK_THREADS) void qk_prep_kernel(__bf16* __restrict_
             if (isk) sk_ += s; else sq_ += s;
         }
     }
-    const float rstd_q = rsqrtf(block_sum_128(sq_, red) / (float)d + eps);
-    const float rstd_k = rsqrtf(block_sum_128(sk_, red) / (float)d + eps);
+    const float rstd_q = rsqrtf(wave_sum(sq_) * inv_d + eps);
+    const float rstd_k = rsqrtf(wave_sum(sk_) * inv_d + eps);
     int pos = positions[tok];
     pos = pos < rope_len ? pos : rope_len - 1;  // host validates; clamp keeps the load in bounds
     const float* cs = rcos + (size_t)pos * 32;
     const float* sn = rsin + (size_t)pos * 32;
 #pragma unroll
-    for (int u = 0; u < QK_MAX_UNITS; ++u) {
-        const int unit = threadIdx.x + u * QK_THREADS;
+    for (int u = 0; u < NU; ++u) {
+        const int unit = lane + u * 64;
         if (unit < nunits) {
             const int isk = unit >= units_half;
             const int uu = unit - isk * units_half;
@@ -158,14 +153,18 @@ __global__ __launch_bounds__(QK_THREADS) void qk_prep_kernel(__bf16* __restrict_
             const float* g = (isk ? gk : gq) + hc;
             const float rs = isk ? rstd_k : rstd_q;
             const float osc = isk ? 1.0f : q_scale;
+            const f32x4 c0 = *(const f32x4*)(cs + j0), c1 = *(const f32x4*)(cs + j0 + 4);
+            const f32x4 s0 = *(const f32x4*)(sn + j0), s1 = *(const f32x4*)(sn + j0 + 4);
+            const f32x4 ga0 = *(const f32x4*)g, ga1 = *(const f32x4*)(g + 4);
+            const f32x4 gb0 = *(const f32x4*)(g + 32), gb1 = *(const f32x4*)(g + 36);
             float o1[8], o2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float x1 = lo[u][e] * rs * g[e];
-                const float x2 = hi[u][e] * rs * g[e + 32];
-                const float c = cs[j0 + e], s = sn[j0 + e];
-                o1[e] = (x1 * c - x2 * s) * osc;
-                o2[e] = (x2 * c + x1 * s) * osc;
+                const float x1 = lo[u][e] * rs * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
+                const float x2 = hi[u][e] * rs * (e < 4 ? gb0[e & 3] : gb1[e & 3]);
+                const float c = e < 4 ? c0[e & 3] : c1[e & 3], sv = e < 4 ? s0[e & 3] : s1[e & 3];
+                o1[e] = (x1 * c - x2 * sv) * osc;
+                o2[e] = (x2 * c + x1 * sv) * osc;
             }
             const int col = isk * d + hc;
             *(u32x4*)(row + col) = u32x4{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]),
@@ -291,11 +290,24 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
                             esmk_stream_t stream) {
     if (!qkv || !gq || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
-    if (8 * H > QK_THREADS * QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: too many heads (%d)", H);
+    const int nu = (8 * H + 63) / 64;
+    if (nu > QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: too many heads (%d)", H);
     if (rope_len <= 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: bad sizes");
     if (M == 0) return ESMK_OK;
-    hipLaunchKernelGGL(qk_prep_kernel, dim3(M), dim3(QK_THREADS), 0, (hipStream_t)stream, (__bf16*)qkv, gq, gk,
-                       positions, rcos, rsin, rope_len, d, H, q_scale, eps);
+    const dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define QK_LAUNCH(NU)                                                                                          \
+    hipLaunchKernelGGL(qk_prep_kernel<NU>, grid, block, 0, s, (__bf16*)qkv, gq, gk, positions, rcos, rsin, rope_len, \
+                       M, d, H, q_scale, eps)
+    switch (nu) {
+        case 1: QK_LAUNCH(1); break;
+        case 2: QK_LAUNCH(2); break;
+        case 3: QK_LAUNCH(3); break;
+        case 4: QK_LAUNCH(4); break;
+        case 5: QK_LAUNCH(5); break;
+        default: QK_LAUNCH(6); break;
+    }
+#undef QK_LAUNCH
     ESMK_CHECK_LAUNCH("esmk_qk_prep");
     return ESMK_OK;
 }
