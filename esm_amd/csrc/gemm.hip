@@ -220,7 +220,9 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
     {
         // large problems: 256x256 ping-pong kernel; small / skinny ones: 128x128 (more, smaller workgroups)
         const int ov = gemm_tile_override();
-        const bool big = (long long)M * N >= 256LL * 256 * 256 && N >= 256 && M >= 256;
+        // measured crossover (tools/gemm_bench.py, M = 512 ... 32768): the 256-tile kernel wins once there are
+        // about half as many 256x256 tiles as CUs; below that the 128-tile kernel fills the chip better.
+        const bool big = (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
         if (ov == 256 || (ov == 0 && big)) {
             // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
             // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call

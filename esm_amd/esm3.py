@@ -169,7 +169,7 @@ class ESM3(nn.Module):
                                          _stream()), "esmk_esm3_encode")
         post, pre, _ = self.transformer(x.view(B, Ln, self.d_model),
                                         None if sequence_id is None else bcast(sequence_id), affine, affine_mask,
-                                        bcast(chain_id))
+                                        bcast(chain_id), return_hiddens=False)
         pn = post.reshape(M, self.d_model)
         out = {name: heads[name].forward(pn).view(B, Ln, -1) for name, _ in _HEADS}
         return ESMOutput(

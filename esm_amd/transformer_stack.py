@@ -100,8 +100,11 @@ class TransformerStack(nn.Module):
     # -- reference signature -----------------------------------------------------------------------
     @torch.no_grad()
     def forward(self, x: torch.Tensor, sequence_id: torch.Tensor | None = None, affine: Affine3D | None = None,
-                affine_mask: torch.Tensor | None = None, chain_id: torch.Tensor | None = None):
-        """x [B, L, d] -> (post_norm, pre_norm, hiddens) in fp32 (transformer_stack.py:64-94)."""
+                affine_mask: torch.Tensor | None = None, chain_id: torch.Tensor | None = None,
+                return_hiddens: bool = True):
+        """x [B, L, d] -> (post_norm, pre_norm, hiddens) in fp32 (transformer_stack.py:64-94).
+
+        return_hiddens=False (not in the reference) skips the n_layers device copies; hiddens is then []."""
         *batch_dims, d = x.shape
         if len(batch_dims) != 2:
             raise ValueError("x must be [B, L, d]")
@@ -121,6 +124,6 @@ class TransformerStack(nn.Module):
             ch = chain_id.reshape(B * Ln).to(torch.int32).contiguous()
         batch = DeviceBatch(pb, dev, aff, am, ch)
         xf = x.to(torch.float32).reshape(B * Ln, d).clone()
-        post, pre, hid = self.engine().forward(xf, batch, want_post=True, want_hiddens=True)
-        hiddens = [hid[i].view(B, Ln, d) for i in range(self.n_layers)]
+        post, pre, hid = self.engine().forward(xf, batch, want_post=True, want_hiddens=return_hiddens)
+        hiddens = [hid[i].view(B, Ln, d) for i in range(self.n_layers)] if return_hiddens else []
         return post.view(B, Ln, d), pre.view(B, Ln, d), hiddens
