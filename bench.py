@@ -85,19 +85,29 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)  # one rank per GPU on a real node; ranks share a GPU only in rehearsals
+    torch.cuda.set_device(dev_index)
     dist = None
+    nccl_ok = False
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # control plane (barrier, max-over-ranks of the elapsed time) on gloo: the timing contract must not depend
+        # on the data-plane collective; RCCL ("nccl") carries only the result all-gather.
+        try:
+            import datetime
+            dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=300))
+            nccl_ok = n_dev >= world
+        except Exception:
+            dist.init_process_group("gloo")
 
     from esm_amd import synth
     from esm_amd.engine import DeviceBatch
     from esm_amd.esmc import ESMC
     from esm_amd.packing import pack_lengths
 
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", dev_index)
     weights = synth.esmc_weights(D_MODEL, N_LAYERS, seed=0)
     model = ESMC(D_MODEL, N_HEADS, N_LAYERS)
     model.load_state_dict(weights)
@@ -108,34 +118,48 @@ def main():
     tokens = synth.synth_tokens([SEQ_LEN] * BATCH, seed=1234 + 1000 * rank).reshape(-1).to(dev)
     batch = DeviceBatch(pack_lengths([SEQ_LEN] * BATCH), dev)
 
-    gather = (world > 1) and not args.no_gather
+    gather = (world > 1) and nccl_ok and not args.no_gather
     side = torch.cuda.Stream() if gather else None
     gathered = torch.empty((world * n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
     send = torch.empty((n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
-    gather_note = "off"
+    gather_note = "off" if (world == 1 or args.no_gather) else ("off: fewer GPUs than ranks" if not nccl_ok else "pending")
+
+    def do_gather(post):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            send.copy_(post)  # fp32 -> bf16 wire format
+            dist.all_gather_into_tensor(gathered, send)
+        post.record_stream(side)
 
     def step():
-        nonlocal gather, gather_note
         logits, post, _ = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=True)
         if gather:
-            try:
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    send.copy_(post)  # fp32 -> bf16 wire format
-                    dist.all_gather_into_tensor(gathered, send)
-                post.record_stream(side)
-                gather_note = "all_gather bf16 embeddings, side stream"
-            except Exception as e:  # keep the measurement alive; say so in the JSON
-                gather = False
-                gather_note = f"failed: {type(e).__name__}: {e}"[:200]
+            do_gather(post)
         return logits
+
+    if gather:  # pre-flight: one gather, fully synchronised, before anything is timed; failure -> measure without it
+        try:
+            _l, post0, _h = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=False)
+            do_gather(post0)
+            side.synchronize()
+            torch.cuda.synchronize()
+            gather_note = "all_gather_into_tensor of bf16 per-residue embeddings on a side stream (RCCL), overlapped with the next step"
+        except Exception as e:
+            gather = False
+            gather_note = f"failed in pre-flight: {type(e).__name__}: {e}"[:200]
+    if dist is not None:  # every rank must agree on whether the collective is part of the step
+        flag = torch.tensor([1.0 if gather else 0.0])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if gather and flag.item() == 0.0:
+            gather = False
+            gather_note = "off: pre-flight failed on another rank"
 
     def sync_all():
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            dist.all_reduce(torch.zeros(1))  # barrier on the gloo control plane (CPU tensor)
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -147,7 +171,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64)  # CPU tensor -> gloo
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -177,7 +201,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line), flush=True)
     if dist is not None:
-        dist.barrier()
+        dist.all_reduce(torch.zeros(1))
         dist.destroy_process_group()
 
 
