@@ -208,6 +208,7 @@ extern "C" int esmk_attn_plan(const int32_t* cu, int n_segments, int32_t* map, i
 
 extern "C" int esmk_attn_varlen(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map,
                                 int n_qblk, int M, int d, int H, esmk_stream_t stream) {
+    if (n_qblk == 0 || M == 0) return ESMK_OK;
     if (!qkv || !ctx || !cu_seqlens || !qblk_map) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen: null pointer");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen: head dim must be 64 (d=%d, heads=%d)", d, H);
     if (n_qblk < 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen: bad sizes");

@@ -207,6 +207,7 @@ extern "C" int esmk_pack_weight(const float* w, void* packed, int N, int K, int 
 
 extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                          float alpha, void* out, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!A || !W || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: null pointer");
     if (M < 0 || N <= 0 || K <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bad shape M=%d N=%d K=%d", M, N, K);
     if (M == 0) return ESMK_OK;

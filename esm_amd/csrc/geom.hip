@@ -222,6 +222,7 @@ __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__
 }  // namespace
 
 extern "C" int esmk_frames(const float* coords, float* affine, uint8_t* mask, int B, int L, esmk_stream_t stream) {
+    if (B == 0 || L == 0) return ESMK_OK;
     if (!coords || !affine || !mask) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_frames: null pointer");
     if (B < 0 || L < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_frames: bad sizes");
     if (B == 0 || L == 0) return ESMK_OK;
@@ -239,6 +240,7 @@ extern "C" int esmk_geom_attn(const float* proj, const float* affine, const uint
                               const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
                               const float* dist_scale, const float* rot_scale, void* out, int ld_out, void* scratch,
                               int M, int H, esmk_stream_t stream) {
+    if (M == 0 || n_rows == 0 || max_row_len == 0) return ESMK_OK;
     if (!proj || !affine || !affine_mask || !seq_id || !chain_id || !row_cu || !dist_scale || !rot_scale || !out || !scratch)
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: null pointer");
     if (M < 0 || H <= 0 || n_rows < 0 || max_row_len < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: bad sizes");

@@ -246,6 +246,7 @@ __global__ void esm3_encode_kernel(esmk_esm3_encoder enc, const int64_t* __restr
 
 extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
                               int M, int d, float eps, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!x || !gamma || !y) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_layernorm: null pointer");
     if (M < 0 || d <= 0 || (d & 3) || d > LN_MAX_VEC * 256)
         ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
@@ -268,6 +269,7 @@ extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, co
 
 extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamma, const float* beta, void* y,
                                   int y_dtype, int M, int d, float eps, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!delta) return esmk_layernorm(x, ESMK_F32, gamma, beta, y, y_dtype, M, d, eps, stream);
     if (!x || !gamma || !y) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add_layernorm: null pointer");
     if (M < 0 || d <= 0 || (d & 3) || d > LN_MAX_VEC * 256)
@@ -288,6 +290,7 @@ extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamm
 extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const int32_t* positions, const float* rcos,
                             const float* rsin, int rope_len, int M, int d, int H, float q_scale, float eps,
                             esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!qkv || !gq || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
     const int nu = (8 * H + 63) / 64;
@@ -314,6 +317,7 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
 
 extern "C" int esmk_embed(const int64_t* tokens, const float* table, int vocab, float* out, int M, int d,
                           esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;  // an empty batch is valid and needs no buffers
     if (!tokens || !table || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_embed: null pointer");
     if (d <= 0 || (d & 3) || vocab <= 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_embed: bad sizes");
     if (M == 0) return ESMK_OK;
@@ -328,6 +332,7 @@ extern "C" int esmk_esm3_encode(const esmk_esm3_encoder* enc, const int64_t* seq
                                 const float* average_plddt, const float* per_res_plddt, const int64_t* ss8,
                                 const int64_t* sasa, const int64_t* function_tokens, const int64_t* residue_tokens,
                                 float* out, int M, int d, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!enc || !sequence || !structure || !average_plddt || !per_res_plddt || !ss8 || !sasa || !function_tokens ||
         !residue_tokens || !out)
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_esm3_encode: null pointer");

@@ -77,7 +77,9 @@ extern "C" size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens) 
 extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
                                   void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
     TRY(validate_trunk(t));
-    if (!b || !x) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null batch or x");
+    if (!b) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null batch");
+    if (b->n_tokens == 0) return ESMK_OK;
+    if (!x) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null x");
     const int M = b->n_tokens, d = t->d_model, H = t->n_heads, h = t->ffn_hidden;
     if (M < 0 || b->n_segments < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: bad batch sizes");
     if (M == 0) return ESMK_OK;
@@ -160,6 +162,7 @@ extern "C" size_t esmk_head_workspace_bytes(int n_tokens, int d_model) {
 
 extern "C" int esmk_head_forward(const esmk_head* hd, const float* x_norm, float* logits, int M, int d, void* workspace,
                                  size_t workspace_bytes, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
     if (!hd || !x_norm || !logits || !hd->w0 || !hd->b0 || !hd->ln_g || !hd->ln_b || !hd->w3 || !hd->b3)
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward: null pointer");
     if (M < 0 || d <= 0 || (d % 64) || hd->out_dim <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward: bad sizes");
