@@ -19,7 +19,8 @@
 namespace {
 
 constexpr int BW = 128;  // output channels per block
-constexpr int BT = 128;  // tokens per block
+// tokens per block: template parameter BT = 128 (default) or 64 (remainder columns of the split dispatch, where
+// 128-token tiles would leave one 4-wave workgroup per CU and nothing to overlap its barrier stalls with)
 constexpr int BK = 64;
 constexpr int TILE_BYTES = 128 * BK * 2;  // 16 KiB per operand tile
 
@@ -28,78 +29,82 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 
-template <int EPI>
+template <int EPI, int BT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ A, int lda,
                                                       const __bf16* __restrict__ W, int ldw, int M, int N,
                                                       int ksteps, const float* __restrict__ bias, float alpha,
-                                                      void* __restrict__ out, int n_ctile, int nblk) {
+                                                      void* __restrict__ out, int n_ctile, int nblk, int ct0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 buffers][W tile | A tile]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int ttile = id / n_ctile, ctile = id - ttile * n_ctile;
-    const int c0 = ctile * BW, t0 = ttile * BT;
+    const int c0 = (ct0 + ctile) * BW, t0 = ttile * BT;  // ct0: first channel tile of this launch (split dispatch)
 
     // ---- staging addresses: wave w owns pieces 4w..4w+3 (8 rows x 128 B each) of both tiles ----
+    constexpr int AP = BT / 32;  // A pieces per wave (a piece = 8 rows x 128 B)
+    constexpr int NJ = BT / 32;  // 16-token MFMA columns per wave
     const __bf16* wsrc[4];
-    const __bf16* asrc[4];
+    const __bf16* asrc[AP];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int p = wave * 4 + i;
-        const int r = p * 8 + (lane >> 3);
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
         const int lc = (lane & 7) ^ ((r >> 1) & 7);
         wsrc[i] = W + (size_t)(c0 + r) * ldw + lc * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int r = (wave * AP + i) * 8 + (lane >> 3);
+        const int lc = (lane & 7) ^ ((r >> 1) & 7);
         int tr = t0 + r;
         tr = tr < M ? tr : M - 1;
         asrc[i] = A + (size_t)tr * lda + lc * 8;
     }
+    constexpr int STAGE_BYTES = TILE_BYTES + BT * 128;
     auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * (2 * TILE_BYTES) + wave * 4096;
+        char* base = smem + buf * STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i] + kt * BK), LDS_PTR(base + i * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK), LDS_PTR(base + TILE_BYTES + i * 1024), 16, 0,
-                                             0);
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(wsrc[i] + kt * BK), LDS_PTR(base + wave * 4096 + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            __builtin_amdgcn_global_load_lds(GLB_PTR(asrc[i] + kt * BK),
+                                             LDS_PTR(base + TILE_BYTES + (wave * AP + i) * 1024), 16, 0, 0);
     };
 
-    const int wr = wave >> 1, wc = wave & 1;  // wave's 64x64 sub-tile: channels wr*64.., tokens wc*64..
-    f32x4 acc[4][4];
+    const int wr = wave >> 1, wc = wave & 1;  // wave's sub-tile: channels wr*64..+63, tokens wc*(BT/2)..
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // fragment read offsets (bytes) inside a tile for kk = 0; kk = 1 flips chunk bit 2
-    int aoff[4], boff[4];
+    int aoff[4], boff[NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ra = wr * 64 + i * 16 + (lane & 15);
-        const int rb = wc * 64 + i * 16 + (lane & 15);
-        aoff[i] = lds_off(ra, lane >> 4);
-        boff[i] = lds_off(rb, lane >> 4);
-    }
+    for (int i = 0; i < 4; ++i) aoff[i] = lds_off(wr * 64 + i * 16 + (lane & 15), lane >> 4);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) boff[j] = lds_off(wc * (BT / 2) + j * 16 + (lane & 15), lane >> 4);
 
     stage(0, 0);
     for (int kt = 0; kt < ksteps; ++kt) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
         if (kt + 1 < ksteps) stage((kt + 1) & 1, kt + 1);
-        const char* wt = smem + (kt & 1) * (2 * TILE_BYTES);
+        const char* wt = smem + (kt & 1) * STAGE_BYTES;
         const char* at = wt + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                af[i] = *(const bf16x8*)(wt + (aoff[i] ^ (kk << 6)));
-                bfr[i] = *(const bf16x8*)(at + (boff[i] ^ (kk << 6)));
-            }
+            for (int i = 0; i < 4; ++i) af[i] = *(const bf16x8*)(wt + (aoff[i] ^ (kk << 6)));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bfr[j] = *(const bf16x8*)(at + (boff[j] ^ (kk << 6)));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
     }
@@ -107,8 +112,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
     // ---- epilogue: acc[i][j][r] = out^T[channel = c0 + wr*64 + i*16 + (lane>>4)*4 + r][token = ... + (lane&15)] ----
     const int q4 = (lane >> 4) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int t = t0 + wc * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < NJ; ++j) {
+        const int t = t0 + wc * (BT / 2) + j * 16 + (lane & 15);
         if (t >= M) continue;
         if constexpr (EPI == ESMK_EPI_SWIGLU) {
 #pragma unroll
@@ -151,21 +156,22 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, __bf16* __restri
     *(u32x4*)(out + (size_t)prow * Kpad + k0) = u32x4{pk[0], pk[1], pk[2], pk[3]};
 }
 
-template <int EPI>
+// Covers channel tiles [ct0, round_up(N,128)/128) of the output.
+template <int EPI, int BT = 128>
 int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
-                hipStream_t s) {
+                hipStream_t s, int ct0 = 0) {
     const int Kpad = round_up(K, BK);
-    const int n_ctile = round_up(N, BW) / BW;
+    const int n_ctile = round_up(N, BW) / BW - ct0;
     const int n_ttile = (M + BT - 1) / BT;
     const int nblk = n_ctile * n_ttile;
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * TILE_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (TILE_BYTES + BT * 128));
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm_kernel<EPI>, dim3(nblk), dim3(256), 4 * TILE_BYTES, s, (const __bf16*)A, lda,
-                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk);
+    hipLaunchKernelGGL((gemm_kernel<EPI, BT>), dim3(nblk), dim3(256), 2 * (TILE_BYTES + BT * 128), s, (const __bf16*)A, lda,
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk, ct0);
     ESMK_CHECK_LAUNCH("esmk_gemm");
     return ESMK_OK;
 }
@@ -173,7 +179,7 @@ int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
 }  // namespace
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
-                 float alpha, void* out, hipStream_t s);
+                 float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s);
 
@@ -234,7 +240,27 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
                 const int rc = esmk_gemm256p(A, lda, W, M, N, K, epilogue, alpha, out, s);
                 if (rc <= 0) return rc;  // 1 = shape not eligible for the persistent kernel
             }
-            return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s);
+            // Split dispatch: when the last 256-channel tile column is at most half full (N = 1152: 4.5 columns)
+            // and dropping it saves a whole round of workgroups over the 256 CUs (640 -> 512 tiles: 3 -> 2
+            // rounds), the 256-kernel covers the full columns and the 128-tile kernel the remaining <= 128
+            // channels; its small workgroups start as soon as CUs drain from the last full round.
+            const int nt = (M + 255) / 256, nc = (N + 255) / 256;
+            const int rem = N - (nc - 1) * 256;
+            static int split_on = -1;
+            if (split_on < 0) { const char* e2 = getenv("ESMK_GEMM_SPLIT"); split_on = e2 ? atoi(e2) : 1; }
+            const bool split = split_on && !persist && nc >= 2 && rem <= 128 && epilogue != ESMK_EPI_SWIGLU &&
+                               (nt * (nc - 1) + 255) / 256 < (nt * nc + 255) / 256;
+            if (!split) return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc);
+            const int rc = esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc - 1);
+            if (rc != ESMK_OK) return rc;
+            const int ct0 = (nc - 1) * 2;
+            switch (epilogue) {
+                case ESMK_EPI_BF16: return launch_gemm<ESMK_EPI_BF16, 64>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
+                case ESMK_EPI_F32: return launch_gemm<ESMK_EPI_F32, 64>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
+                case ESMK_EPI_RESIDUAL: return launch_gemm<ESMK_EPI_RESIDUAL, 64>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
+                case ESMK_EPI_BIAS_GELU: return launch_gemm<ESMK_EPI_BIAS_GELU, 64>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
+                default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
+            }
         }
     }
     switch (epilogue) {

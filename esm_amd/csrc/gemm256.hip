@@ -325,9 +325,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
 
 template <int EPI>
 int launch(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
-           hipStream_t s) {
+           hipStream_t s, int n_ctile) {
     const int Kpad = round_up(K, BK);
-    const int n_ctile = round_up(N, TB) / TB;
     const int n_ttile = (M + TB - 1) / TB;
     const int nblk = n_ctile * n_ttile;
     static int gt = 0;
@@ -348,14 +347,15 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, const flo
 }  // namespace
 
 // Called by esmk_gemm (gemm.hip) for large problems.  W must be packed with rows padded to 256.
+// Computes the first n_ctile 256-channel tile columns (all of them, or all but the last under split dispatch).
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
-                 float alpha, void* out, hipStream_t s) {
+                 float alpha, void* out, hipStream_t s, int n_ctile) {
     switch (epilogue) {
-        case ESMK_EPI_BF16: return launch<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s);
-        case ESMK_EPI_F32: return launch<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s);
-        case ESMK_EPI_SWIGLU: return launch<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s);
-        case ESMK_EPI_RESIDUAL: return launch<ESMK_EPI_RESIDUAL>(A, lda, W, M, N, K, bias, alpha, out, s);
-        case ESMK_EPI_BIAS_GELU: return launch<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s);
+        case ESMK_EPI_BF16: return launch<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+        case ESMK_EPI_F32: return launch<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+        case ESMK_EPI_SWIGLU: return launch<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+        case ESMK_EPI_RESIDUAL: return launch<ESMK_EPI_RESIDUAL>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+        case ESMK_EPI_BIAS_GELU: return launch<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
     }
 }
