@@ -1,82 +1,148 @@
 // Row-wise, HBM-bound kernels: LayerNorm, QK-LayerNorm + rotary, embedding gathers.
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace {
 
+// Grid of a persistent row kernel: as many 256-thread blocks as the device holds at once (CUs x occupancy),
+// queried once per kernel instantiation, capped by the number of 4-row groups.
+template <typename K>
+int persistent_blocks(K kernel, size_t lds_bytes, int row_groups, int max_per_cu) {
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds_bytes) != hipSuccess || per_cu < 1) per_cu = 2;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (per_cu > max_per_cu) per_cu = max_per_cu;
+    return min(row_groups, cus * per_cu);
+}
+
 // --------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (two-pass mean / variance in fp32).
+// Persistent waves: each wave walks rows wave_id, wave_id + n_waves, ... and issues the loads of its NEXT row
+// before it reduces / normalises / stores the current one, so a wave always has a whole row in flight
+// (a plain one-row-per-wave grid measured 2.9 TB/s on the fp32 -> bf16 pass: latency-bound).  gamma / beta are
+// staged once per block in LDS.  NV = float4 vectors per lane (compile time: the row stays in registers).
 // --------------------------------------------------------------------------------------------------
 constexpr int LN_MAX_VEC = 16;  // 16 float4 per lane -> d <= 4096
 
+template <typename TIN>
+struct LnRaw { using type = u32x2; };  // 4 bf16
+template <>
+struct LnRaw<float> { using type = f32x4; };
+
+__device__ __forceinline__ f32x4 ln_cvt(const f32x4 v) { return v; }
+__device__ __forceinline__ f32x4 ln_cvt(const u32x2 p) {
+    return f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u), __uint_as_float(p.y << 16),
+                 __uint_as_float(p.y & 0xffff0000u)};
+}
+
 // ADD: x (f32, in/out) += delta (bf16) before normalising; the updated row is written back to x.
-template <typename TIN, typename TOUT, bool ADD = false>
-__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* __restrict__ x, const float* __restrict__ gamma,
+template <typename TIN, typename TOUT, bool ADD, int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOUT* __restrict__ y, int M,
-                                                        int d, int ldy, float eps,
-                                                        const __bf16* __restrict__ delta = nullptr) {
+                                                        int d, int ldy, float eps, const __bf16* __restrict__ delta) {
+    extern __shared__ __attribute__((aligned(16))) float gb[];  // gamma[d] | beta[d]
+    using RAW = typename LnRaw<TIN>::type;
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
     const int nvec = d >> 2;  // d % 4 == 0
-    f32x4 v[LN_MAX_VEC];
-    float sum = 0.f;
-#pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nvec) {
-            if constexpr (sizeof(TIN) == 4) {
-                v[i] = *(const f32x4*)((const float*)x + (size_t)row * d + c * 4);
-            } else {
-                const u32x2 p = *(const u32x2*)((const __bf16*)x + (size_t)row * d + c * 4);
-                v[i] = f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u),
-                             __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
-            }
-            if constexpr (ADD) {
-                const u32x2 p = *(const u32x2*)(delta + (size_t)row * d + c * 4);
-                v[i] += f32x4{__uint_as_float(p.x << 16), __uint_as_float(p.x & 0xffff0000u),
-                              __uint_as_float(p.y << 16), __uint_as_float(p.y & 0xffff0000u)};
-                *(f32x4*)((float*)x + (size_t)row * d + c * 4) = v[i];
-            }
-            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-        }
+    for (int c = threadIdx.x; c < nvec; c += 256) {
+        *(f32x4*)(gb + c * 4) = *(const f32x4*)(gamma + c * 4);
+        *(f32x4*)(gb + d + c * 4) = beta ? *(const f32x4*)(beta + c * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    const float mean = wave_sum(sum) / (float)d;
-    float sq = 0.f;
+    __syncthreads();
+    const int stride = gridDim.x * 4;
+    int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    RAW xr[NV];
+    u32x2 dr[NV];
+    auto load_row = [&](int r) {
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nvec) {
-            v[i] -= mean;
-            sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                // streamed once: x is next touched a whole sub-block later, delta never again
+                xr[i] = __builtin_nontemporal_load((const RAW*)(x + (size_t)r * d + c * 4));
+                if constexpr (ADD) dr[i] = __builtin_nontemporal_load((const u32x2*)(delta + (size_t)r * d + c * 4));
+            }
         }
-    }
-    const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+    };
+    if (row < M) load_row(row);
+    for (; row < M; row += stride) {
+        f32x4 v[NV];
+        float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAX_VEC; ++i) {
-        const int c = lane + i * 64;
-        if (c < nvec) {
-            const f32x4 g = *(const f32x4*)(gamma + c * 4);
-            f32x4 o = v[i] * rstd * g;
-            if (beta) o += *(const f32x4*)(beta + c * 4);
-            if constexpr (sizeof(TOUT) == 4) {
-                *(f32x4*)((float*)y + (size_t)row * ldy + c * 4) = o;
-            } else {
-                u32x2 p;
-                p.x = pack_bf16x2(o[0], o[1]);
-                p.y = pack_bf16x2(o[2], o[3]);
-                *(u32x2*)((__bf16*)y + (size_t)row * ldy + c * 4) = p;
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nvec) {
+                v[i] = ln_cvt(xr[i]);
+                if constexpr (ADD) {
+                    v[i] += ln_cvt(dr[i]);
+                    __builtin_nontemporal_store(v[i], (f32x4*)((float*)x + (size_t)row * d + c * 4));
+                }
+                sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+            }
+        }
+        if (row + stride < M) load_row(row + stride);  // next row in flight while this one is reduced and stored
+        const float mean = wave_sum(sum) / (float)d;
+        float sq = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                v[i] -= mean;
+                sq += (v[i][0] * v[i][0] + v[i][1] * v[i][1]) + (v[i][2] * v[i][2] + v[i][3] * v[i][3]);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(sq) / (float)d + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + i * 64;
+            if (c < nvec) {
+                const f32x4 o = v[i] * rstd * *(const f32x4*)(gb + c * 4) + *(const f32x4*)(gb + d + c * 4);
+                if constexpr (sizeof(TOUT) == 4) {
+                    *(f32x4*)((float*)y + (size_t)row * ldy + c * 4) = o;
+                } else {
+                    u32x2 p;
+                    p.x = pack_bf16x2(o[0], o[1]);
+                    p.y = pack_bf16x2(o[2], o[3]);
+                    *(u32x2*)((__bf16*)y + (size_t)row * ldy + c * 4) = p;
+                }
             }
         }
     }
 }
 
+template <typename TIN, typename TOUT, bool ADD>
+void launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int d, float eps,
+                      const void* delta, hipStream_t s) {
+    const int nv = (d / 4 + 63) / 64;
+    const size_t lds = (size_t)2 * d * sizeof(float);
+#define LN_LAUNCH(NV)                                                                                                \
+    do {                                                                                                             \
+        static int cap = 0; /* resident blocks on the device; measured flat from 2 to 5 per CU, use at most 4 */    \
+        if (cap == 0) cap = persistent_blocks(layernorm_kernel<TIN, TOUT, ADD, NV>, lds, 1 << 30, 4);                \
+        hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, ADD, NV>), dim3(min((M + 3) / 4, cap)), dim3(256), lds, s,   \
+                           (const TIN*)x, gamma, beta, (TOUT*)y, M, d, d, eps, (const __bf16*)delta);                \
+    } while (0)
+    if (nv <= 2) LN_LAUNCH(2);
+    else if (nv <= 4) LN_LAUNCH(4);
+    else if (nv <= 5) LN_LAUNCH(5);
+    else if (nv <= 6) LN_LAUNCH(6);
+    else if (nv <= 8) LN_LAUNCH(8);
+    else if (nv <= 10) LN_LAUNCH(10);
+    else LN_LAUNCH(16);
+#undef LN_LAUNCH
+}
+
 // --------------------------------------------------------------------------------------------------
 // QK-LayerNorm (over the full d_model width, bias-free) + NeoX rotary per 64-wide head, in place.
-// One WAVE per token (4 tokens per 256-thread block): the q and k rows live in registers, statistics are
-// wave shuffles - no LDS, no block barrier.  A "unit" is (q|k, head, 8-column chunk c in 0..3) and covers
-// columns [8c, 8c+8) and their rotary partners [32+8c, 32+8c+8) of that head: 8*H units per token.
+// One WAVE per token: the q and k rows live in registers, statistics are wave shuffles - no LDS, no block
+// barrier.  A "unit" is one 16-byte chunk (8 columns) of the token's contiguous [q | k] row: lane L owns chunks
+// L, L+64, ... so every load / store instruction of the wave covers 1 KiB of contiguous memory.  The rotary
+// partner of a column (j <-> j+32 inside a head) lives 4 chunks away = in lane L^4 of the same unit.
+// Persistent waves with the next token's row in flight (see layernorm_kernel).
 // --------------------------------------------------------------------------------------------------
-constexpr int QK_MAX_UNITS = 6;  // per lane -> 8*H <= 384 -> H <= 48
+constexpr int QK_MAX_UNITS = 12;  // per lane -> 16*H <= 768 -> H <= 48
 
 __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 #pragma unroll
@@ -86,7 +152,7 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
     }
 }
 
-template <int NU>  // units per lane (compile-time so the row stays in registers)
+template <int NU>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
 __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
                                                       const float* __restrict__ gk,
                                                       const int* __restrict__ positions,
@@ -94,83 +160,94 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
                                                       const float* __restrict__ rsin, int rope_len, int M, int d,
                                                       int H, float q_scale, float eps) {
     const int lane = threadIdx.x & 63;
-    const int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (tok >= M) return;
-    __bf16* row = qkv + (size_t)tok * 3 * d;
-    const int units_half = 4 * H;  // units for q; same count for k
+    const int units_half = 8 * H;  // chunks of q; same count for k
     const int nunits = 2 * units_half;
-    float lo[NU][8], hi[NU][8];
-    float sq_ = 0.f, sk_ = 0.f;
+    const int stride = gridDim.x * 4;
+    int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
+    // Only the LAST unit of a lane can fall outside the row (NU = ceil(nunits/64)): its lanes read chunk 0 again
+    // and are masked out of the statistics and the store, so that no other unit needs a per-lane guard.
+    const bool last_on = lane + (NU - 1) * 64 < nunits;
+    const float last_w = last_on ? 1.0f : 0.0f;
+    int uoff[NU];   // element offset of the unit inside the token's [q | k] row
+    float kw[NU];   // 1.0 for a k chunk, 0.0 for a q chunk
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         const int unit = lane + u * 64;
-        if (unit < nunits) {
-            const int isk = unit >= units_half;
-            const int uu = unit - isk * units_half;
-            const int col = isk * d + (uu >> 2) * 64 + (uu & 3) * 8;
-            unpack8(*(const u32x4*)(row + col), lo[u]);
-            unpack8(*(const u32x4*)(row + col + 32), hi[u]);
-            float s = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s += lo[u][e] + hi[u][e];
-            if (isk) sk_ += s; else sq_ += s;
-        }
+        const bool on = (u < NU - 1) || last_on;
+        uoff[u] = on ? unit * 8 : 0;
+        kw[u] = (on && unit >= units_half) ? 1.0f : 0.0f;
     }
+    u32x4 raw[NU];
+    int pos_next = 0;
+    auto load_tok = [&](int t) {
+        const __bf16* row = qkv + (size_t)t * 3 * d;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) raw[u] = *(const u32x4*)(row + uoff[u]);
+        pos_next = positions[t];
+    };
+    if (tok < M) load_tok(tok);
     const float inv_d = 1.0f / (float)d;
-    const float mean_q = wave_sum(sq_) * inv_d;
-    const float mean_k = wave_sum(sk_) * inv_d;
-    sq_ = 0.f; sk_ = 0.f;
+    const int j0 = (lane & 3) * 8;                 // rotary frequency index of this lane's element 0
+    const float sgn = (lane & 4) ? 1.0f : -1.0f;   // first half: x1*c - x2*s; second half: x2*c + x1*s
+    for (; tok < M; tok += stride) {
+        __bf16* row = qkv + (size_t)tok * 3 * d;
+        float v[NU][8];
+        float st = 0.f, sk = 0.f;  // sum over q and k together, and over k alone
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int unit = lane + u * 64;
-        if (unit < nunits) {
-            const int isk = unit >= units_half;
-            const float m = isk ? mean_k : mean_q;
+        for (int u = 0; u < NU; ++u) {
+            unpack8(raw[u], v[u]);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[u][e];
+            if (u == NU - 1) s *= last_w;
+            st += s;
+            sk += s * kw[u];
+        }
+        int pos = pos_next;
+        if (tok + stride < M) load_tok(tok + stride);
+        st = wave_sum(st);
+        sk = wave_sum(sk);
+        const float mean_k = sk * inv_d, mean_q = (st - sk) * inv_d;
+        st = 0.f; sk = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float m = kw[u] != 0.f ? mean_k : mean_q;
             float s = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                lo[u][e] -= m;
-                hi[u][e] -= m;
-                s += lo[u][e] * lo[u][e] + hi[u][e] * hi[u][e];
+                v[u][e] -= m;
+                s += v[u][e] * v[u][e];
             }
-            if (isk) sk_ += s; else sq_ += s;
+            if (u == NU - 1) s *= last_w;
+            st += s;
+            sk += s * kw[u];
         }
-    }
-    const float rstd_q = rsqrtf(wave_sum(sq_) * inv_d + eps);
-    const float rstd_k = rsqrtf(wave_sum(sk_) * inv_d + eps);
-    int pos = positions[tok];
-    pos = pos < rope_len ? pos : rope_len - 1;  // host validates; clamp keeps the load in bounds
-    const float* cs = rcos + (size_t)pos * 32;
-    const float* sn = rsin + (size_t)pos * 32;
+        st = wave_sum(st);
+        sk = wave_sum(sk);
+        const float rstd_k = rsqrtf(sk * inv_d + eps);
+        const float rstd_q = rsqrtf((st - sk) * inv_d + eps) * q_scale;
+        pos = pos < rope_len ? pos : rope_len - 1;  // host validates; clamp keeps the load in bounds
+        const float* cs = rcos + (size_t)pos * 32 + j0;
+        const float* sn = rsin + (size_t)pos * 32 + j0;
+        const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4);
+        const f32x4 s0 = *(const f32x4*)sn * sgn, s1 = *(const f32x4*)(sn + 4) * sgn;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int unit = lane + u * 64;
-        if (unit < nunits) {
-            const int isk = unit >= units_half;
-            const int uu = unit - isk * units_half;
-            const int hc = (uu >> 2) * 64 + (uu & 3) * 8;  // column inside q (or k)
-            const int j0 = (uu & 3) * 8;                   // rotary frequency index of element 0
-            const float* g = (isk ? gk : gq) + hc;
+        for (int u = 0; u < NU; ++u) {
+            // every lane takes part in the exchange: the partner lane L^4 is in range whenever L is (nunits % 8 == 0)
+            const bool isk = kw[u] != 0.f;
+            const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
             const float rs = isk ? rstd_k : rstd_q;
-            const float osc = isk ? 1.0f : q_scale;
-            const f32x4 c0 = *(const f32x4*)(cs + j0), c1 = *(const f32x4*)(cs + j0 + 4);
-            const f32x4 s0 = *(const f32x4*)(sn + j0), s1 = *(const f32x4*)(sn + j0 + 4);
-            const f32x4 ga0 = *(const f32x4*)g, ga1 = *(const f32x4*)(g + 4);
-            const f32x4 gb0 = *(const f32x4*)(g + 32), gb1 = *(const f32x4*)(g + 36);
-            float o1[8], o2[8];
+            const f32x4 ga = *(const f32x4*)g * rs, gb = *(const f32x4*)(g + 4) * rs;
+            float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float x1 = lo[u][e] * rs * (e < 4 ? ga0[e & 3] : ga1[e & 3]);
-                const float x2 = hi[u][e] * rs * (e < 4 ? gb0[e & 3] : gb1[e & 3]);
-                const float c = e < 4 ? c0[e & 3] : c1[e & 3], sv = e < 4 ? s0[e & 3] : s1[e & 3];
-                o1[e] = (x1 * c - x2 * sv) * osc;
-                o2[e] = (x2 * c + x1 * sv) * osc;
+                const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]);
+                const float pn = __shfl_xor(n, 4);
+                o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
             }
-            const int col = isk * d + hc;
-            *(u32x4*)(row + col) = u32x4{pack_bf16x2(o1[0], o1[1]), pack_bf16x2(o1[2], o1[3]),
-                                         pack_bf16x2(o1[4], o1[5]), pack_bf16x2(o1[6], o1[7])};
-            *(u32x4*)(row + col + 32) = u32x4{pack_bf16x2(o2[0], o2[1]), pack_bf16x2(o2[2], o2[3]),
-                                              pack_bf16x2(o2[4], o2[5]), pack_bf16x2(o2[6], o2[7])};
+            if (u < NU - 1 || last_on)
+                *(u32x4*)(row + uoff[u]) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                 pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         }
     }
 }
@@ -252,15 +329,14 @@ extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, co
         ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
     if (M == 0) return ESMK_OK;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((M + 3) / 4), block(256);
     if (x_dtype == ESMK_F32 && y_dtype == ESMK_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<float, __bf16>), grid, block, 0, s, (const float*)x, gamma, beta, (__bf16*)y, M, d, d, eps);
+        launch_layernorm<float, __bf16, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_F32 && y_dtype == ESMK_F32)
-        hipLaunchKernelGGL((layernorm_kernel<float, float>), grid, block, 0, s, (const float*)x, gamma, beta, (float*)y, M, d, d, eps);
+        launch_layernorm<float, float, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_BF16 && y_dtype == ESMK_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<__bf16, __bf16>), grid, block, 0, s, (const __bf16*)x, gamma, beta, (__bf16*)y, M, d, d, eps);
+        launch_layernorm<__bf16, __bf16, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_BF16 && y_dtype == ESMK_F32)
-        hipLaunchKernelGGL((layernorm_kernel<__bf16, float>), grid, block, 0, s, (const __bf16*)x, gamma, beta, (float*)y, M, d, d, eps);
+        launch_layernorm<__bf16, float, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_layernorm: bad dtype");
     ESMK_CHECK_LAUNCH("esmk_layernorm");
@@ -276,11 +352,10 @@ extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamm
         ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_add_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
     if (M == 0) return ESMK_OK;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid((M + 3) / 4), block(256);
     if (y_dtype == ESMK_BF16)
-        hipLaunchKernelGGL((layernorm_kernel<float, __bf16, true>), grid, block, 0, s, (const float*)x, gamma, beta, (__bf16*)y, M, d, d, eps, (const __bf16*)delta);
+        launch_layernorm<float, __bf16, true>(x, gamma, beta, y, M, d, eps, delta, s);
     else if (y_dtype == ESMK_F32)
-        hipLaunchKernelGGL((layernorm_kernel<float, float, true>), grid, block, 0, s, (const float*)x, gamma, beta, (float*)y, M, d, d, eps, (const __bf16*)delta);
+        launch_layernorm<float, float, true>(x, gamma, beta, y, M, d, eps, delta, s);
     else
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add_layernorm: bad dtype");
     ESMK_CHECK_LAUNCH("esmk_add_layernorm");
@@ -293,22 +368,30 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
     if (M == 0) return ESMK_OK;
     if (!qkv || !gq || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
-    const int nu = (8 * H + 63) / 64;
+    const int nu = (16 * H + 63) / 64;
     if (nu > QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: too many heads (%d)", H);
     if (rope_len <= 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: bad sizes");
     if (M == 0) return ESMK_OK;
-    const dim3 grid((M + 3) / 4), block(256);
+    const dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
+    /* grid = exactly the blocks the device holds at once (3 per CU for 18 heads): measured best */
 #define QK_LAUNCH(NU)                                                                                          \
-    hipLaunchKernelGGL(qk_prep_kernel<NU>, grid, block, 0, s, (__bf16*)qkv, gq, gk, positions, rcos, rsin, rope_len, \
-                       M, d, H, q_scale, eps)
+    do {                                                                                                       \
+        static int cap = 0;                                                                                    \
+        if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
+        hipLaunchKernelGGL(qk_prep_kernel<NU>, dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, gk, \
+                           positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                            \
+    } while (0)
     switch (nu) {
         case 1: QK_LAUNCH(1); break;
         case 2: QK_LAUNCH(2); break;
         case 3: QK_LAUNCH(3); break;
         case 4: QK_LAUNCH(4); break;
         case 5: QK_LAUNCH(5); break;
-        default: QK_LAUNCH(6); break;
+        case 6: QK_LAUNCH(6); break;
+        case 7: case 8: QK_LAUNCH(8); break;
+        case 9: case 10: QK_LAUNCH(10); break;
+        default: QK_LAUNCH(12); break;
     }
 #undef QK_LAUNCH
     ESMK_CHECK_LAUNCH("esmk_qk_prep");
