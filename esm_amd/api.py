@@ -11,6 +11,30 @@ import torch
 
 
 @dataclass
+class ESMProtein:
+    """Sequence-level view of the reference's ESMProtein (esm/sdk/api.py:37-60): the fields the trunk path uses.
+    Structure / function annotation handling (PDB I/O, ProteinChain) is out of scope."""
+    sequence: str | None = None
+    secondary_structure: str | None = None
+    sasa: list | None = None
+    coordinates: torch.Tensor | None = None
+    plddt: torch.Tensor | None = None
+    ptm: torch.Tensor | None = None
+    potential_sequence_of_concern: bool = False
+
+    def __len__(self) -> int:
+        if self.sequence is not None:
+            return len(self.sequence)
+        if self.secondary_structure is not None:
+            return len(self.secondary_structure)
+        if self.sasa is not None:
+            return len(self.sasa)
+        if self.coordinates is not None:
+            return self.coordinates.size(0)
+        raise ValueError("No track to determine length from.")
+
+
+@dataclass
 class ESMProteinTensor:
     sequence: torch.Tensor | None = None
     structure: torch.Tensor | None = None

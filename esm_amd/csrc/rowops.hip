@@ -266,6 +266,29 @@ __global__ void embed_kernel(const int64_t* __restrict__ tokens, const float* __
     *(f32x4*)(out + (size_t)t * d + c * 4) = *(const f32x4*)(table + (size_t)tok * d + c * 4);
 }
 
+// Mean over the rows of every segment: block = (segment, 64-column slab); 16 row groups x 16 lanes x float4,
+// rows strided by 16, row groups combined through LDS.  Empty segments give zeros.
+__global__ __launch_bounds__(256) void segment_mean_kernel(const float* __restrict__ x, int ldx,
+                                                           const int* __restrict__ cu, float* __restrict__ out,
+                                                           int d) {
+    __shared__ f32x4 part[16][16];
+    const int seg = blockIdx.x;
+    const int c = blockIdx.y * 64 + (threadIdx.x & 15) * 4;
+    const int rg = threadIdx.x >> 4;
+    const int r0 = cu[seg], r1 = cu[seg + 1];
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c < d)
+        for (int r = r0 + rg; r < r1; r += 16) acc += *(const f32x4*)(x + (size_t)r * ldx + c);
+    part[rg][threadIdx.x & 15] = acc;
+    __syncthreads();
+    if (rg == 0 && c < d) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) acc += part[k][threadIdx.x];
+        const float inv = r1 > r0 ? 1.0f / (float)(r1 - r0) : 0.f;
+        *(f32x4*)(out + (size_t)seg * d + c) = acc * inv;
+    }
+}
+
 __device__ __forceinline__ long long clampi(long long v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
 
 __global__ void esm3_encode_kernel(esmk_esm3_encoder enc, const int64_t* __restrict__ seq,
@@ -395,6 +418,18 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
     }
 #undef QK_LAUNCH
     ESMK_CHECK_LAUNCH("esmk_qk_prep");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_segment_mean(const float* x, int ldx, const int32_t* cu_seqlens, int n_segments, float* out, int d,
+                                 esmk_stream_t stream) {
+    if (n_segments == 0) return ESMK_OK;
+    if (!x || !cu_seqlens || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_segment_mean: null pointer");
+    if (n_segments < 0 || d <= 0 || (d & 3) || ldx < d || (ldx & 3))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_segment_mean: d and ldx must be multiples of 4, ldx >= d");
+    hipLaunchKernelGGL(segment_mean_kernel, dim3(n_segments, (d + 63) / 64), dim3(256), 0, (hipStream_t)stream, x, ldx,
+                       cu_seqlens, out, d);
+    ESMK_CHECK_LAUNCH("esmk_segment_mean");
     return ESMK_OK;
 }
 

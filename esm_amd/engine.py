@@ -180,6 +180,16 @@ class TrunkEngine:
         return post, x, hid
 
 
+def segment_mean(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
+    """Mean of x f32 [N, d] over the row ranges cu int32 [S+1] (device) -> [S, d] (esmk_segment_mean)."""
+    assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and cu.dtype == torch.int32
+    S = cu.numel() - 1
+    out = torch.empty((S, x.shape[1]), dtype=torch.float32, device=x.device)
+    L.check(L.lib().esmk_segment_mean(L.ptr(x), x.stride(0), L.ptr(cu), S, L.ptr(out), x.shape[1], _stream()),
+            "esmk_segment_mean")
+    return out
+
+
 class HeadEngine:
     """RegressionHead (reference esm/layers/regression_head.py:17-22) on esmk_head_forward."""
 

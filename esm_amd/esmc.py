@@ -13,8 +13,9 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
-from .api import ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
-from .engine import DeviceBatch, HeadEngine, _stream
+from .api import ESMProtein, ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
+from .engine import DeviceBatch, HeadEngine, _stream, segment_mean
+from .tokenization import EsmSequenceTokenizer, decode_sequence, stack_variable_length_tensors, tokenize_sequence
 from .packing import PackedBatch, pack_sequence_id
 from .transformer_stack import TransformerStack
 
@@ -40,7 +41,7 @@ class ESMC(nn.Module):
         self.embed = nn.Embedding(64, d_model)
         self.transformer = TransformerStack(d_model, n_heads, None, n_layers, n_layers_geom=0)
         self.sequence_head = RegressionHeadParams(d_model, 64)
-        self.tokenizer = tokenizer
+        self.tokenizer = tokenizer if tokenizer is not None else EsmSequenceTokenizer()
         self.d_model = d_model
         self._head = None
         self._embed_f32 = None
@@ -85,9 +86,30 @@ class ESMC(nn.Module):
         logits = head.forward(post) if want_logits else None
         return logits, post, hid
 
+    # ---- text <-> tokens (reference esmc.py:100-115,175-192) ----------------------------------
+    def _tokenize(self, sequence: list[str]) -> torch.Tensor:
+        pad = self.tokenizer.pad_token_id
+        return stack_variable_length_tensors(
+            [tokenize_sequence(x, self.tokenizer, add_special_tokens=True) for x in sequence],
+            constant_value=pad).to(self.device)
+
+    def _detokenize(self, sequence: torch.Tensor) -> list[str]:
+        pad = self.tokenizer.pad_token_id
+        assert sequence.ndim == 2
+        return [decode_sequence(x[x != pad][1:-1], self.tokenizer) for x in sequence]
+
+    def encode(self, input: ESMProtein) -> ESMProteinTensor:
+        tokens = self._tokenize([input.sequence])[0] if input.sequence is not None else None
+        return ESMProteinTensor(sequence=tokens,
+                                potential_sequence_of_concern=input.potential_sequence_of_concern).to(self.device)
+
+    def decode(self, input: ESMProteinTensor) -> ESMProtein:
+        assert input.sequence is not None
+        return ESMProtein(sequence=self._detokenize(input.sequence[None] if input.sequence.ndim == 1 else input.sequence)[0])
+
     @torch.no_grad()
     def forward(self, sequence_tokens: torch.Tensor | None = None, sequence_id: torch.Tensor | None = None,
-                return_hidden_states: bool = True) -> ESMCOutput:
+                return_hidden_states: bool = True, _means: dict | None = None) -> ESMCOutput:
         assert sequence_tokens is not None and sequence_tokens.ndim == 2
         B, Ln = sequence_tokens.shape
         dev = sequence_tokens.device
@@ -105,6 +127,11 @@ class ESMC(nn.Module):
         else:
             gidx, tok = None, flat.contiguous()
         logits, post, hid = self.forward_packed(tok, batch, want_hiddens=return_hidden_states)
+        if _means is not None:  # per-row means over the kept tokens, on the packed tensors (esmk_segment_mean)
+            if _means.get("embedding"):
+                _means["embedding"] = segment_mean(post, batch.row_cu)
+            if _means.get("hidden") and hid is not None:
+                _means["hidden"] = torch.stack([segment_mean(hid[i], batch.row_cu) for i in range(hid.shape[0])])
 
         def unpack(t):  # [N, w] -> [B, L, w] with zeros at dropped positions
             if gidx is None:
@@ -128,11 +155,17 @@ class ESMC(nn.Module):
         """reference esmc.py:194-225."""
         if not isinstance(input, _BatchedESMProteinTensor):
             input = _BatchedESMProteinTensor.from_protein_tensor(input)
-        out = self.forward(sequence_tokens=input.sequence, return_hidden_states=config.return_hidden_states)
-        hs = out.hidden_states
-        if hs is not None and config.ith_hidden_layer != -1:
-            hs = hs[config.ith_hidden_layer: config.ith_hidden_layer + 1]
+        want_hid = config.return_hidden_states or config.return_mean_hidden_states
+        means = {"embedding": config.return_mean_embedding, "hidden": config.return_mean_hidden_states}
+        out = self.forward(sequence_tokens=input.sequence, return_hidden_states=want_hid, _means=means)
+        hs, mh = out.hidden_states, means["hidden"] if config.return_mean_hidden_states else None
+        if config.ith_hidden_layer != -1:
+            sl = slice(config.ith_hidden_layer, config.ith_hidden_layer + 1)
+            hs = hs[sl] if hs is not None else None
+            mh = mh[sl] if mh is not None else None
         return LogitsOutput(
             logits=ForwardTrackData(sequence=out.sequence_logits if config.sequence else None),
             embeddings=out.embeddings if config.return_embeddings else None,
-            hidden_states=hs if config.return_hidden_states else None)
+            mean_embedding=means["embedding"] if config.return_mean_embedding else None,
+            hidden_states=hs if config.return_hidden_states else None,
+            mean_hidden_state=mh)

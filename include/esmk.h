@@ -240,6 +240,15 @@ int esmk_head_forward(const esmk_head* h, const float* x_norm, float* logits, in
                       size_t workspace_bytes, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Output side: mean over the residues of every segment (LogitsConfig.return_mean_embedding /
+ * return_mean_hidden_states, esm/sdk/api.py:391-392; cookbook/tutorials/2_embed.ipynb pools hidden states with
+ * torch.mean(dim=-2)).  x f32 [n_tokens, ldx] packed, cu_seqlens device int32 [n_segments+1],
+ * out f32 [n_segments, d]; an empty segment gives zeros.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_segment_mean(const float* x, int ldx, const int32_t* cu_seqlens, int n_segments, float* out, int d,
+                      esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Timing helpers (thin wrappers over hipEvent*, so that a harness without HIP headers can time kernels on
  * the stream they are launched on).  No counterpart in the reference.
  * ------------------------------------------------------------------------------------------ */

@@ -167,9 +167,52 @@ def frames_case(name):
     save(name, kind="frames", coords=_np(coords), affine=_np(affine.tensor), mask=_np(mask))
 
 
+TOKENIZER_STRINGS = [
+    "ACDEFGHIKLMNPQRSTVWY", "ACD_EF", "AC|DE", "acdX", "A C", "BUZO.-", "<mask>AC<eos>", "", "J", "A<unk>C",
+    "\u00e9A", "AC<pad>D", "<cls>A", "A\nC", "A<maskC", "__", "MKT|_LLV<mask>", "X" * 70,
+]
+FASTA_TEXT = """# comment line
+>sp|P1 first protein
+MKTAYIAK
+QRQISFVK
+
+>second
+ACD_EF|GH
+>empty_record
+>last  \t
+  WW
+"""
+
+
+def text_cases():
+    """Input-side fixtures: the reference tokenizer (sequence_tokenizer.py + encoding.py:35-45 + decoding.py:125-135
+    restated: utils/decoding cannot be imported here, circular import through esm.sdk) and FASTA parser."""
+    import json
+    ref_import.install()
+    from esm.tokenization.sequence_tokenizer import EsmSequenceTokenizer
+    from esm.utils import encoding
+    from esm.utils.parsing import parse_fasta
+    tok = EsmSequenceTokenizer()
+    cases = []
+    for s in TOKENIZER_STRINGS:
+        ids = encoding.tokenize_sequence(s, tok).tolist()
+        cases.append({"text": s, "ids": ids, "ids_nospecial": encoding.tokenize_sequence(s, tok, add_special_tokens=False).tolist(),
+                      "hf_decode": tok.decode(ids)})
+    fasta = [[e.header, e.sequence] for e in parse_fasta(FASTA_TEXT)]
+    attrs = {k: getattr(tok, k) for k in ("pad_token_id", "mask_token_id", "cls_token_id", "eos_token_id", "bos_token_id",
+                                          "unk_token_id", "vocab_size")}
+    attrs["chain_break_token_id"] = tok.convert_tokens_to_ids("|")
+    with open(os.path.join(OUT, "text_inputs.json"), "w") as f:
+        json.dump({"tokenizer": cases, "tokenizer_attrs": attrs, "fasta_text": FASTA_TEXT, "fasta_entries": fasta}, f, indent=1)
+    print("text_inputs.json written")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
+    if "--text-only" in sys.argv:
+        return text_cases()
+    text_cases()
     # (i) tiny ESMC under the three sequence_id dialects
     esmc_case("esmc_tiny_bool", 128, 2, 3, [33, 48, 17, 40], wseed=11, tseed=100)
     row0, sid0 = packed_row([20, 31, 9], 64)

@@ -73,7 +73,7 @@ def c3(B=16, L=512):
     struct = torch.randint(0, 4096, (B, L), generator=g).cuda()
     coords = synth.synth_backbone(B, L, seed=3).cuda()
     fn = lambda: m(sequence_tokens=seq, structure_tokens=struct, structure_coords=coords)
-    dt = timed(fn, 5, 2)
+    dt = timed(fn, 5 if B > 1 else 20, 2)
     n = B * L
     fl = flop_per_token(d, 4096, NL, L) + 2 * d * (15 * VH + 3 * VH) + 5 * 2 * d * d + 2 * d * (4096 + 11 + 19 + 2080 + 1478)
     return {"config": f"C3 ESM3-open-shaped (48 layers, geometric block 0), {B} x {L}, seq+struct+coords, all 6 heads",
@@ -124,6 +124,6 @@ def c5(B=4, L=4096, NL=80):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c1", "c3", "c4", "c5"]
     for w in which:
-        r = {"c1": c1, "c3": c3, "c4": c4, "c5": c5}[w]()
+        r = {"c1": c1, "c3": c3, "c3b1": lambda: c3(B=1), "c4": c4, "c5": c5}[w]()
         print(json.dumps(r), flush=True)
         torch.cuda.empty_cache()
