@@ -110,7 +110,9 @@ class ESM3(nn.Module):
     @torch.no_grad()
     def forward(self, *, sequence_tokens=None, structure_tokens=None, ss8_tokens=None, sasa_tokens=None,
                 function_tokens=None, residue_annotation_tokens=None, average_plddt=None, per_res_plddt=None,
-                structure_coords=None, chain_id=None, sequence_id=None) -> ESMOutput:
+                structure_coords=None, chain_id=None, sequence_id=None, _heads=None) -> ESMOutput:
+        """reference esm3.py:299-374.  _heads (private): names of the output heads to evaluate (default all six);
+        the sampling loop asks for one."""
         try:
             Bx, Ln, device = next((x.shape[0], x.shape[1], x.device) for x in
                                   [sequence_tokens, structure_tokens, ss8_tokens, sasa_tokens, structure_coords,
@@ -171,11 +173,13 @@ class ESM3(nn.Module):
                                         None if sequence_id is None else bcast(sequence_id), affine, affine_mask,
                                         bcast(chain_id), return_hiddens=False)
         pn = post.reshape(M, self.d_model)
-        out = {name: heads[name].forward(pn).view(B, Ln, -1) for name, _ in _HEADS}
+        out = {name: (heads[name].forward(pn).view(B, Ln, -1) if _heads is None or name in _heads else None)
+               for name, _ in _HEADS}
+        fl = out["function_head"]
         return ESMOutput(
             sequence_logits=out["sequence_head"], structure_logits=out["structure_head"],
             secondary_structure_logits=out["ss8_head"], sasa_logits=out["sasa_head"],
-            function_logits=out["function_head"].view(B, Ln, 8, 260), residue_logits=out["residue_head"],
+            function_logits=None if fl is None else fl.view(B, Ln, 8, 260), residue_logits=out["residue_head"],
             embeddings=pre)
 
     def logits(self, input: ESMProteinTensor | _BatchedESMProteinTensor,
@@ -186,7 +190,10 @@ class ESM3(nn.Module):
         per_res_plddt = None
         if input.coordinates is not None:
             per_res_plddt = input.coordinates.isfinite().all(dim=-1).any(dim=-1).float()
-        o = self.forward(sequence_tokens=input.sequence, structure_tokens=input.structure,
+        want = {"sequence_head": config.sequence, "structure_head": config.structure,
+                "ss8_head": config.secondary_structure, "sasa_head": config.sasa, "function_head": config.function,
+                "residue_head": config.residue_annotations}
+        o = self.forward(_heads={k for k, v in want.items() if v},sequence_tokens=input.sequence, structure_tokens=input.structure,
                          ss8_tokens=input.secondary_structure, sasa_tokens=input.sasa, function_tokens=input.function,
                          residue_annotation_tokens=input.residue_annotations,
                          average_plddt=torch.tensor(1.0, device=input.device), per_res_plddt=per_res_plddt,
@@ -200,3 +207,68 @@ class ESM3(nn.Module):
                 function=o.function_logits if config.function else None),
             residue_annotation_logits=o.residue_logits if config.residue_annotations else None,
             embeddings=o.embeddings if config.return_embeddings else None)
+
+    # ---- iterative decoding of one track (reference ESM3.generate -> iterative_sampling_tokens,
+    #      esm3.py:417-470, utils/generation.py:355-534) --------------------------------------------
+    _TRACK_IDS = {  # track -> (BOS, EOS, PAD, MASK) ids used to fill a missing track (esm3 constants :7-31)
+        "sequence": (0, 2, 1, 32), "structure": (4098, 4097, 4099, 4096),
+        "secondary_structure": (0, 0, 0, 0), "sasa": (0, 0, 0, 0)}
+
+    def generate_tokens(self, prompts, config, generator=None):
+        """Fill the masked positions of `config.track` for a list of ESMProteinTensor prompts (any lengths).
+
+        Other tracks present in a prompt condition the model and are returned unchanged; a missing target track
+        starts fully masked.  Returns a list of ESMProteinTensor with the decoded track."""
+        from .sampling import default_track_tokenizers, iterative_sampling
+        if isinstance(prompts, ESMProteinTensor):
+            prompts = [prompts]
+        track = config.track
+        if track in ("coordinates", "residue_annotations"):
+            raise ValueError(f"Iterative sampling {track} is not supported.")
+        if track not in self._TRACK_IDS:
+            raise NotImplementedError(f"track {track!r} cannot be generated here (needs tokenizer data files)")
+        dev = self.device
+        lens = [len(p) for p in prompts]
+        Ln = max(lens)
+        fields = ("sequence", "structure", "secondary_structure", "sasa")
+
+        def stack(name):
+            rows = [getattr(p, name) for p in prompts]
+            if all(r is None for r in rows) and name != track:
+                return None
+            bos, eos, pad, mask = self._TRACK_IDS[name]
+            out = torch.full((len(prompts), Ln), pad, dtype=torch.int64, device=dev)
+            for i, (r, n) in enumerate(zip(rows, lens)):
+                if r is None:
+                    out[i, :n] = mask
+                    out[i, 0], out[i, n - 1] = bos, eos
+                else:
+                    out[i, :n] = r.to(dev)
+            return out
+
+        tracks = {name: stack(name) for name in fields}
+        coords = None
+        if any(p.coordinates is not None for p in prompts):
+            coords = torch.full((len(prompts), Ln, 3, 3), float("nan"), device=dev)
+            for i, p in enumerate(prompts):
+                if p.coordinates is not None:
+                    coords[i, :lens[i]] = p.coordinates[..., :3, :].to(dev)
+        if config.condition_on_coordinates_only and coords is not None and track != "structure":
+            tracks["structure"] = None  # generation.py:367-370
+        cfg_field = {"sequence": "sequence", "structure": "structure", "secondary_structure": "secondary_structure", "sasa": "sasa"}[track]
+
+        def logits_fn(cur):
+            t = dict(tracks)
+            t[track] = cur
+            inp = _BatchedESMProteinTensor(sequence=t["sequence"], structure=t["structure"],
+                                           secondary_structure=t["secondary_structure"], sasa=t["sasa"], coordinates=coords)
+            return getattr(self.logits(inp, LogitsConfig(**{cfg_field: True})).logits, track)
+
+        tok = default_track_tokenizers()[track]
+        done = iterative_sampling(logits_fn, tracks[track], lens, config, tok, generator=generator)
+        outs = []
+        for i, p in enumerate(prompts):
+            q = ESMProteinTensor(**{f.name: getattr(p, f.name) for f in __import__("dataclasses").fields(ESMProteinTensor)})
+            setattr(q, track, done[i, :lens[i]].clone())
+            outs.append(q)
+        return outs

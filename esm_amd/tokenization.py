@@ -58,8 +58,13 @@ class EsmSequenceTokenizer:
         return self.cls_token
 
     @property
-    def special_token_ids(self):
-        return [self.cls_token_id, self.pad_token_id, self.mask_token_id, self.eos_token_id, self.chain_break_token_id]
+    def all_token_ids(self):
+        return list(range(self.vocab_size))
+
+    @property
+    def special_token_ids(self):  # HF all_special_ids of the reference tokenizer: eos, unk, pad, cls, mask, "|"
+        return [self.eos_token_id, self.unk_token_id, self.pad_token_id, self.cls_token_id, self.mask_token_id,
+                self.chain_break_token_id]
 
     # ---- single sequences ---------------------------------------------------------------------
     def _body(self, sequence: str, lut: np.ndarray) -> np.ndarray:

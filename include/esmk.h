@@ -249,6 +249,22 @@ int esmk_segment_mean(const float* x, int ldx, const int32_t* cu_seqlens, int n_
                       esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sampling step of the iterative decoding loop (esm/utils/generation.py:703-733,786-822 and
+ * esm/utils/sampling.py:153-200,293-313 fused into one pass per row).
+ *   logits  f32 [R, V], MODIFIED IN PLACE exactly as the reference modifies its logits tensor: entries outside
+ *           the top-p nucleus become finfo(float32).min, invalid ids become -inf
+ *   valid   u8 [V] (1 = may be sampled) or NULL
+ *   noise   f32 [R, V] of Exp(1) draws (what torch.multinomial draws internally: id = argmax(softmax(l/T)/q));
+ *           ignored / may be NULL when temperature == 0 (argmax)
+ *   tokens, sampling_mask  current ids and 0/1 mask [R] (both or neither): rows with mask 0 keep their token and
+ *           report logprob 0, as torch.where(sampling_mask, sampled, tokens) does
+ *   outputs [R]: sampled ids, entropy and top probability of softmax(modified logits), log-prob of the chosen id
+ * ------------------------------------------------------------------------------------------ */
+int esmk_sample_track(float* logits, int R, int V, const uint8_t* valid, float temperature, float top_p,
+                      const float* noise, const int64_t* tokens, const uint8_t* sampling_mask, int64_t* sampled,
+                      float* entropy, float* logprob, float* top_prob, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Timing helpers (thin wrappers over hipEvent*, so that a harness without HIP headers can time kernels on
  * the stream they are launched on).  No counterpart in the reference.
  * ------------------------------------------------------------------------------------------ */

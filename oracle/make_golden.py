@@ -202,9 +202,93 @@ def text_cases():
     attrs = {k: getattr(tok, k) for k in ("pad_token_id", "mask_token_id", "cls_token_id", "eos_token_id", "bos_token_id",
                                           "unk_token_id", "vocab_size")}
     attrs["chain_break_token_id"] = tok.convert_tokens_to_ids("|")
+    attrs["all_token_ids"] = list(tok.all_token_ids)
+    attrs["special_token_ids"] = sorted(tok.special_token_ids)
     with open(os.path.join(OUT, "text_inputs.json"), "w") as f:
         json.dump({"tokenizer": cases, "tokenizer_attrs": attrs, "fasta_text": FASTA_TEXT, "fasta_entries": fasta}, f, indent=1)
     print("text_inputs.json written")
+
+
+def sampling_cases():
+    """Sampler fixtures from the reference's own _sample_track / step-mask / annealing functions
+    (esm/utils/generation.py:241-352,703-822, esm/utils/sampling.py:153-343)."""
+    ref_import.install()
+    import esm.sdk.api as api  # noqa: F401  (must precede esm.utils.generation: circular import otherwise)
+    from esm.sdk.api import GenerationConfig, SamplingTrackConfig
+    from esm.utils import generation as G
+    from esm.utils.sampling import _BatchedESMProteinTensor
+    from esm.tokenization.sequence_tokenizer import EsmSequenceTokenizer
+    from esm.tokenization.structure_tokenizer import StructureTokenizer
+    from types import SimpleNamespace
+    out = {}
+    g = torch.Generator().manual_seed(7)
+    n_case = 0
+    for V, mask_idx, specials in ((64, 32, [0, 1, 2, 31, 32]), (4101, 4096, [4096, 4097, 4098, 4099, 4100])):
+        for temperature, top_p, only_masked, seed in ((0.0, 1.0, True, 0), (0.0, 0.6, False, 0), (0.7, 1.0, True, 11),
+                                                      (1.3, 0.8, True, 12)):
+            B, L = (2, 24) if V == 64 else (2, 10)  # keep the 4101-wide fixtures small
+            logits = torch.randn(B, L, V, generator=g) * 3.0
+            tokens = torch.randint(4, 24 if V == 64 else 4000, (B, L), generator=g)
+            tokens[:, 0] = specials[0] if V == 64 else 4098
+            tokens[:, -1] = specials[2] if V == 64 else 4097
+            tokens[0, 3:L - 2] = mask_idx
+            tokens[1, 5:9] = mask_idx
+            tokens[1, L - 3] = specials[1]  # a pad / special inside the row
+            invalid = [5, 9] if V == 64 else [17, 300]
+            valid_ids = sorted(set(range(V if V == 64 else 4101)) - set(specials) - set(invalid))
+            if V == 64:
+                valid_ids = [v for v in valid_ids if v < 33]  # tokenizer vocabulary is 33 wide, logits 64
+            cfg = SamplingTrackConfig(temperature=temperature, top_p=top_p, only_sample_masked_tokens=only_masked,
+                                      invalid_ids=invalid, topk_logprobs=0)
+            lg = logits.clone()
+            torch.manual_seed(seed)
+            meta = G._sample_track(lg, tokens, cfg, mask_idx, valid_ids)
+            torch.manual_seed(seed)
+            noise = torch.empty(B * L, V).exponential_(1)  # what torch.multinomial draws first (n_sample == 1 path)
+            if temperature > 0:  # pin the noise recipe: multinomial(probs, 1) == argmax(probs / q)
+                probs = torch.softmax(lg.reshape(-1, V) / temperature, -1)
+                smask = G.get_sampling_mask(tokens, cfg, mask_idx).reshape(-1)
+                redraw = (probs / noise).argmax(-1)
+                assert torch.equal(redraw[smask], meta["sampled_tokens"].reshape(-1)[smask]), "noise recipe mismatch"
+            k = f"st{n_case}_"
+            out.update({k + "logits": _np(logits), k + "tokens": _np(tokens), k + "valid_ids": np.asarray(valid_ids),
+                        k + "invalid_ids": np.asarray(invalid), k + "mask_idx": mask_idx, k + "temperature": temperature,
+                        k + "top_p": top_p, k + "only_masked": only_masked, k + "noise": _np(noise),
+                        k + "logits_after": _np(lg), k + "sampled": _np(meta["sampled_tokens"]),
+                        k + "entropy": _np(meta["entropy"]), k + "logprob": _np(meta["logprob"]),
+                        k + "prob": _np(meta["prob"]), k + "top_prob": _np(meta["top_prob"])})
+            n_case += 1
+    out["n_sample_track"] = n_case
+    # step masks: which masked positions are unmasked at step t (entropy strategy is deterministic)
+    toks = SimpleNamespace(sequence=EsmSequenceTokenizer(), structure=StructureTokenizer())
+    n_mask = 0
+    for track, mask_idx, L, n_masked, num_steps, schedule in (("sequence", 32, 40, 30, 8, "cosine"),
+                                                              ("structure", 4096, 33, 31, 5, "linear"),
+                                                              ("sequence", 32, 20, 3, 3, "cosine")):
+        tokens = torch.randint(4, 24, (1, L), generator=g)
+        tokens[0, 0], tokens[0, -1] = (0, 2) if track == "sequence" else (4098, 4097)
+        pos = torch.randperm(L - 2, generator=g)[:n_masked] + 1
+        tokens[0, pos] = mask_idx
+        cur = tokens.clone()
+        ent = torch.rand(1, L, generator=g)
+        cfg = GenerationConfig(track=track, num_steps=num_steps, schedule=schedule, strategy="entropy")
+        wheres = []
+        for t in range(num_steps):
+            prot = _BatchedESMProteinTensor(**{track: cur})
+            w = G._get_iterative_sampling_mask_for_prompt_and_step(
+                prot, torch.tensor(L), torch.tensor(n_masked), t, api.ForwardTrackData(**{track: ent}), cfg, toks)
+            wheres.append(_np(w))
+            cur = torch.where(w, torch.full_like(cur, 5), cur)
+        k = f"sm{n_mask}_"
+        out.update({k + "track": track, k + "mask_idx": mask_idx, k + "tokens": _np(tokens), k + "entropy": _np(ent),
+                    k + "num_steps": num_steps, k + "schedule": schedule, k + "n_masked": n_masked,
+                    k + "where": np.stack(wheres)})
+        n_mask += 1
+    out["n_step_mask"] = n_mask
+    out["annealed"] = np.asarray([[G._get_annealed_temperature(t, n, T) for t in range(n)]
+                                  for n, T in ((1, 1.0), (8, 0.7), (8, 1.5))][1:], dtype=np.float64)
+    out["annealed_n1"] = G._get_annealed_temperature(0, 1, 1.0)
+    save("sampling", **out)
 
 
 def main():
@@ -212,7 +296,10 @@ def main():
     torch.set_num_threads(8)
     if "--text-only" in sys.argv:
         return text_cases()
+    if "--sampling-only" in sys.argv:
+        return sampling_cases()
     text_cases()
+    sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
     esmc_case("esmc_tiny_bool", 128, 2, 3, [33, 48, 17, 40], wseed=11, tseed=100)
     row0, sid0 = packed_row([20, 31, 9], 64)

@@ -1,0 +1,107 @@
+"""esmk_sample_track against outputs of the reference's _sample_track (tests/golden/sampling.npz: argmax and
+seeded multinomial cases, with the Exp(1) noise torch.multinomial drew), and the decoding loop end to end."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling.npz"))
+FMIN = float(np.finfo(np.float32).min)
+
+
+@pytest.mark.parametrize("i", range(int(G["n_sample_track"])))
+def test_sample_track_matches_reference(i):
+    from esm_amd.sampling import SamplingTrackConfig, sample_track
+    k = f"st{i}_"
+    logits = torch.from_numpy(G[k + "logits"]).cuda().contiguous()
+    tokens = torch.from_numpy(G[k + "tokens"]).cuda()
+    cfg = SamplingTrackConfig(temperature=float(G[k + "temperature"]), top_p=float(G[k + "top_p"]),
+                              only_sample_masked_tokens=bool(G[k + "only_masked"]), invalid_ids=G[k + "invalid_ids"].tolist())
+    noise = torch.from_numpy(G[k + "noise"]).cuda()
+    out = sample_track(logits, tokens, cfg, int(G[k + "mask_idx"]), G[k + "valid_ids"].tolist(), noise=noise)
+    assert np.array_equal(out["sampled_tokens"].cpu().numpy(), G[k + "sampled"])
+    after, want_after = logits.cpu().numpy(), G[k + "logits_after"]
+    assert np.array_equal(np.isneginf(after), np.isneginf(want_after))         # invalid ids
+    assert np.array_equal(after == FMIN, want_after == FMIN)                     # outside the top-p nucleus
+    keep = np.isfinite(want_after) & (want_after != FMIN)
+    assert np.array_equal(after[keep], want_after[keep])                         # everything else untouched
+    for name, tol in (("entropy", 2e-5), ("logprob", 2e-5), ("prob", 2e-6), ("top_prob", 2e-6)):
+        np.testing.assert_allclose(out[name].cpu().numpy(), G[k + name], rtol=1e-4, atol=tol, err_msg=name)
+
+
+def test_sample_track_errors_and_device_noise():
+    from esm_amd._lib import EsmkError
+    from esm_amd.sampling import SamplingTrackConfig, sample_track
+    logits = torch.randn(1, 6, 64, device="cuda")
+    tokens = torch.tensor([[0, 32, 32, 5, 32, 2]], device="cuda")
+    with pytest.raises(ValueError):
+        sample_track(logits, tokens, SamplingTrackConfig(), 32, [])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    a = sample_track(logits.clone(), tokens, SamplingTrackConfig(temperature=1.0), 32, list(range(4, 24)), generator=g)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    b = sample_track(logits.clone(), tokens, SamplingTrackConfig(temperature=1.0), 32, list(range(4, 24)), generator=g)
+    assert torch.equal(a["sampled_tokens"], b["sampled_tokens"])
+    s = a["sampled_tokens"][0]
+    assert s[0] == 0 and s[3] == 5 and s[5] == 2 and all(4 <= int(s[j]) < 24 for j in (1, 2, 4))
+    with pytest.raises(EsmkError):
+        sample_track(torch.randn(1, 2, 20000, device="cuda"), torch.zeros(1, 2, dtype=torch.long, device="cuda"),
+                     SamplingTrackConfig(temperature=0.0), 0, [1])
+
+
+def test_multinomial_distribution():
+    """Many rows with the same logits: empirical frequencies follow softmax(l / T)."""
+    from esm_amd.sampling import SamplingTrackConfig, sample_track
+    V, R = 16, 20000
+    base = torch.linspace(-2, 2, V)
+    logits = base.expand(1, R, V).contiguous().cuda()
+    tokens = torch.full((1, R), 15, device="cuda")
+    cfg = SamplingTrackConfig(temperature=0.5, only_sample_masked_tokens=False)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    out = sample_track(logits, tokens, cfg, 15, list(range(V)), generator=g)
+    ids = out["sampled_tokens"][0, 1:-1].cpu()
+    freq = torch.bincount(ids, minlength=V).float() / ids.numel()
+    want = torch.softmax(base / 0.5, -1)
+    assert (freq - want).abs().max() < 0.01
+
+
+def test_generate_sequence_with_esm3():
+    from esm_amd import synth
+    from esm_amd.api import ESMProteinTensor
+    from esm_amd.esm3 import ESM3
+    from esm_amd.sampling import GenerationConfig
+    m = ESM3(128, 2, 8, 2)
+    m.load_state_dict(synth.esm3_weights(128, 2, 8, seed=51))
+    m = m.cuda()
+    seq_a = torch.tensor([0] + [32] * 20 + [2])
+    seq_b = torch.tensor([0, 5, 6, 32, 32, 32, 7, 8, 32, 2])
+    struct_b = torch.tensor([4098] + [100] * 8 + [4097])
+    prompts = [ESMProteinTensor(sequence=seq_a), ESMProteinTensor(sequence=seq_b, structure=struct_b)]
+    cfg = GenerationConfig(track="sequence", num_steps=4, temperature=0.7)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    out = m.generate_tokens(prompts, cfg, generator=g)
+    for p, o in zip(prompts, out):
+        s = o.sequence.cpu()
+        assert s.shape == p.sequence.shape and not (s == 32).any()
+        keep = p.sequence != 32
+        assert torch.equal(s[keep], p.sequence[keep])          # prompt residues untouched
+        new = s[~keep]
+        assert ((new >= 4) & (new <= 30)).all()                 # only non-special vocabulary ids
+    assert out[1].structure is struct_b or torch.equal(out[1].structure, struct_b)
+    # entropy strategy at temperature ~0 is deterministic
+    cfg2 = GenerationConfig(track="sequence", num_steps=3, temperature=0.0, temperature_annealing=False, strategy="entropy")
+    o1 = m.generate_tokens(prompts, cfg2)
+    o2 = m.generate_tokens(prompts, cfg2)
+    assert all(torch.equal(a.sequence, b.sequence) for a, b in zip(o1, o2))
+    # a missing target track starts fully masked: structure tokens for a sequence-only prompt
+    cfg3 = GenerationConfig(track="structure", num_steps=2, temperature=0.0, temperature_annealing=False, strategy="entropy")
+    o3 = m.generate_tokens([ESMProteinTensor(sequence=seq_b)], cfg3)[0]
+    st = o3.structure.cpu()
+    assert st[0] == 4098 and st[-1] == 4097 and (st[1:-1] < 4096).all()
+    with pytest.raises(ValueError):
+        m.generate_tokens(prompts, GenerationConfig(track="coordinates"))
+    with pytest.raises(NotImplementedError):
+        m.generate_tokens(prompts, GenerationConfig(track="function"))
+    with pytest.raises(ValueError):
+        m.generate_tokens([ESMProteinTensor(sequence=torch.tensor([0, 5, 6, 2]))], GenerationConfig(track="sequence"))
