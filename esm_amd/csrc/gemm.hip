@@ -29,8 +29,12 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 }
 
 
-template <int EPI, int BT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__ A, int lda,
+constexpr int EPI_PARTIAL = 100;  // split-K: fp32 partial sums [split][M][n_ctile*128], no epilogue
+
+// NS = LDS stages: 2 (two workgroups per CU overlap each other's barrier stalls) or 4 (one workgroup per CU with
+// three K-steps of loads in flight: small grids, where every K-step otherwise pays a full memory latency)
+template <int EPI, int BT, int NS = 2>
+__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(const __bf16* __restrict__ A, int lda,
                                                       const __bf16* __restrict__ W, int ldw, int M, int N,
                                                       int ksteps, const float* __restrict__ bias, float alpha,
                                                       void* __restrict__ out, int n_ctile, int nblk, int ct0) {
@@ -38,6 +42,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
+    // split-K: blockIdx.y = split index; this workgroup reduces K-steps [kt0, kt1) of its tile
+    const int kt0 = (EPI == EPI_PARTIAL) ? (int)((long long)ksteps * blockIdx.y / gridDim.y) : 0;
+    const int kt1 = (EPI == EPI_PARTIAL) ? (int)((long long)ksteps * (blockIdx.y + 1) / gridDim.y) : ksteps;
     const int id = xcd_remap(blockIdx.x, nblk);
     const int ttile = id / n_ctile, ctile = id - ttile * n_ctile;
     const int c0 = (ct0 + ctile) * BW, t0 = ttile * BT;  // ct0: first channel tile of this launch (split dispatch)
@@ -87,12 +94,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
 #pragma unroll
     for (int j = 0; j < NJ; ++j) boff[j] = lds_off(wc * (BT / 2) + j * 16 + (lane & 15), lane >> 4);
 
-    stage(0, 0);
-    for (int kt = 0; kt < ksteps; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile kt landed for every wave; everyone is done reading the other buffer
-        if (kt + 1 < ksteps) stage((kt + 1) & 1, kt + 1);
-        const char* wt = smem + (kt & 1) * STAGE_BYTES;
+    constexpr int LPS = 4 + AP;  // global_load_lds per wave and stage
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (kt0 + i < kt1) stage(i, kt0 + i);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        // wait for this wave's loads of stage kt: all but the stages issued after it may stay in flight
+        if constexpr (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int after = min(NS - 2, kt1 - 1 - kt);
+            if (after >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPS) : "memory");
+            else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();  // stage kt landed for every wave; everyone is done reading the buffer refilled next
+        if (kt + NS - 1 < kt1) stage((kt + NS - 1 - kt0) % NS, kt + NS - 1);
+        const char* wt = smem + ((kt - kt0) % NS) * STAGE_BYTES;
         const char* at = wt + TILE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -115,7 +133,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const __bf16* __restrict__
     for (int j = 0; j < NJ; ++j) {
         const int t = t0 + wc * (BT / 2) + j * 16 + (lane & 15);
         if (t >= M) continue;
-        if constexpr (EPI == ESMK_EPI_SWIGLU) {
+        if constexpr (EPI == EPI_PARTIAL) {
+            const int ldp = n_ctile * BW;  // ct0 == 0 here
+            float* o = (float*)out + ((size_t)blockIdx.y * M + t) * ldp + c0 + wr * 64 + q4;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *(f32x4*)(o + i * 16) = acc[i][j];
+        } else if constexpr (EPI == ESMK_EPI_SWIGLU) {
 #pragma unroll
             for (int i = 0; i < 4; i += 2)
                 epi_swiglu4(acc[i][j], acc[i + 1][j], t, ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4, N >> 1, out);
@@ -176,6 +199,71 @@ int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     return ESMK_OK;
 }
 
+// Split-K second pass: sum the fp32 partials of every split in a fixed order (deterministic) and apply the
+// epilogue.  One thread per 4 consecutive output channels of one token.
+template <int EPI>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, int S, int M, int N, int ldp,
+                                                            const float* __restrict__ bias, float alpha,
+                                                            void* __restrict__ out) {
+    const int ow4 = ((EPI == ESMK_EPI_SWIGLU ? (N >> 1) : N) + 3) >> 2;  // groups of 4 output channels per token
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)M * ow4) return;
+    const int t = (int)(idx / ow4), c = (int)(idx - (size_t)t * ow4) * 4;
+    const size_t sstride = (size_t)M * ldp;
+    if constexpr (EPI == ESMK_EPI_SWIGLU) {
+        // output channel c -> packed gate row (c/16)*32 + c%16, up row = gate row + 16 (esmk_pack_weight)
+        const float* p = part + (size_t)t * ldp + (c >> 4) * 32 + (c & 15);
+        f32x4 g = f32x4{0.f, 0.f, 0.f, 0.f}, u = g;
+        for (int s = 0; s < S; ++s) {
+            g += *(const f32x4*)(p + s * sstride);
+            u += *(const f32x4*)(p + s * sstride + 16);
+        }
+        epi_swiglu4(g, u, t, c, N >> 1, out);
+    } else {
+        const float* p = part + (size_t)t * ldp + c;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < S; ++s) v += *(const f32x4*)(p + s * sstride);
+        epi_store4<EPI>(v, t, c, N, bias, alpha, out);
+    }
+}
+
+// How many K splits a small problem gets: enough workgroups for ~1.5 per CU, at least 4 K-steps each.
+int splitk_factor(int M, int N, int K) {
+    const int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    const int ksteps = round_up(K, BK) / BK;
+    if (tiles >= 192 || ksteps < 8) return 1;
+    int s = 384 / tiles;
+    if (s > ksteps / 4) s = ksteps / 4;
+    if (s > 8) s = 8;
+    return s < 2 ? 1 : s;
+}
+
+template <int EPI>
+int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
+                  hipStream_t s, int S, float* part) {
+    const int Kpad = round_up(K, BK);
+    const int n_ctile = round_up(N, BW) / BW;
+    const int n_ttile = (M + 127) / 128;
+    const int nblk = n_ctile * n_ttile;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_PARTIAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  4 * TILE_BYTES);
+        attr_done = true;
+    }
+    // two stages, two workgroups per CU: measured faster than four stages at one workgroup per CU (ESM3 1 x 512:
+    // 6.9 vs 8.0 ms per forward) - with one wave per SIMD nothing overlaps the LDS reads with the MFMAs
+    hipLaunchKernelGGL((gemm_kernel<EPI_PARTIAL, 128>), dim3(nblk, S), dim3(256), 4 * TILE_BYTES, s, (const __bf16*)A, lda,
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, nullptr, 1.f, (void*)part, n_ctile, nblk, 0);
+    ESMK_CHECK_LAUNCH("esmk_gemm(split-K)");
+    const int ow4 = ((EPI == ESMK_EPI_SWIGLU ? (N >> 1) : N) + 3) >> 2;
+    const size_t total = (size_t)M * ow4;
+    hipLaunchKernelGGL(splitk_reduce_kernel<EPI>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, part, S, M, N,
+                       n_ctile * BW, bias, alpha, out);
+    ESMK_CHECK_LAUNCH("esmk_gemm(split-K reduce)");
+    return ESMK_OK;
+}
+
 }  // namespace
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
@@ -211,8 +299,19 @@ extern "C" int esmk_pack_weight(const float* w, void* packed, int N, int K, int 
     return ESMK_OK;
 }
 
+extern "C" size_t esmk_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
+    const int S = splitk_factor(M, N, K);
+    return S > 1 ? (size_t)S * M * round_up(N, BW) * sizeof(float) : 0;
+}
+
 extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                          float alpha, void* out, esmk_stream_t stream) {
+    return esmk_gemm_ws(A, lda, W, M, N, K, epilogue, bias, alpha, out, nullptr, 0, stream);
+}
+
+extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                            float alpha, void* out, void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;
     if (!A || !W || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: null pointer");
     if (M < 0 || N <= 0 || K <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bad shape M=%d N=%d K=%d", M, N, K);
@@ -261,6 +360,21 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
                 case ESMK_EPI_BIAS_GELU: return launch_gemm<ESMK_EPI_BIAS_GELU, 64>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
                 default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
             }
+        }
+    }
+    // small problems: split K over several workgroups per tile when the caller lent a workspace for the partials
+    // (not for the read-modify-write residual epilogue: its output is also an input)
+    static int splitk_on = -1;
+    if (splitk_on < 0) { const char* e3 = getenv("ESMK_GEMM_SPLITK"); splitk_on = e3 ? atoi(e3) : 1; }
+    const int S = (splitk_on && workspace && epilogue != ESMK_EPI_RESIDUAL && gemm_tile_override() == 0) ? splitk_factor(M, N, K) : 1;
+    if (S > 1 && workspace_bytes >= esmk_gemm_workspace_bytes(M, N, K) && !((uintptr_t)workspace & 15)) {
+        float* part = (float*)workspace;
+        switch (epilogue) {
+            case ESMK_EPI_BF16: return launch_splitk<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s, S, part);
+            case ESMK_EPI_F32: return launch_splitk<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s, S, part);
+            case ESMK_EPI_SWIGLU: return launch_splitk<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s, S, part);
+            case ESMK_EPI_BIAS_GELU: return launch_splitk<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s, S, part);
+            default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
         }
     }
     switch (epilogue) {

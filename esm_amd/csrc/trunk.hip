@@ -26,7 +26,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TrunkWs {
-    size_t xn, qkv, ctx, hbuf, dbuf, gproj, gout, gscratch, total;
+    size_t xn, qkv, ctx, hbuf, dbuf, gproj, gout, gscratch, splitk, splitk_bytes, total;
 };
 
 TrunkWs trunk_layout(const esmk_trunk* t, int M) {
@@ -46,6 +46,12 @@ TrunkWs trunk_layout(const esmk_trunk* t, int M) {
         w.gout = off;     off += align256((size_t)M * round_up(3 * (int)vh, 64) * 2);
         w.gscratch = off; off += align256(esmk_geom_scratch_bytes(M, (int)vh));
     }
+    // split-K partials of the small-M GEMMs (0 bytes for large batches)
+    size_t sk = 0;
+    auto need = [&](int N, int K) { const size_t b = esmk_gemm_workspace_bytes(M, N, K); if (b > sk) sk = b; };
+    need(3 * (int)d, (int)d); need((int)d, (int)d); need(2 * (int)h, (int)d); need((int)d, (int)h);
+    if (geom) { need(15 * t->v_heads, (int)d); need((int)d, 3 * t->v_heads); }
+    w.splitk = off; w.splitk_bytes = sk; off += align256(sk);
     w.total = off;
     return w;
 }
@@ -104,6 +110,7 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
     // folded into the fp32 stream by the NEXT LayerNorm pass (esmk_add_layernorm): x is read and written once
     // per sub-block instead of twice, and every big GEMM ends in a coalesced bf16 store.
     void* dbuf = ws + w.dbuf;
+    void* skp = w.splitk_bytes ? (void*)(ws + w.splitk) : nullptr;
     const void* pending = nullptr;  // delta not yet added to x
     for (int i = 0; i < t->n_layers; ++i) {
         const esmk_layer& L = t->layers[i];
@@ -115,10 +122,10 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
             if (hipMemcpyAsync(hiddens + (size_t)(i - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
                 ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
         }
-        TRY(esmk_gemm(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, stream));
+        TRY(esmk_gemm_ws(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, skp, w.splitk_bytes, stream));
         TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
         TRY(esmk_attn_varlen(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, stream));
-        TRY(esmk_gemm(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+        TRY(esmk_gemm_ws(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
         pending = dbuf;
         // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)
         if (L.geom_ln_g) {
@@ -131,18 +138,18 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
             void* gout = ws + w.gout;
             const int ldg = round_up(3 * vh, 64);
             TRY(esmk_add_layernorm(x, pending, L.geom_ln_g, nullptr, xn, ESMK_BF16, M, d, eps, stream));
-            TRY(esmk_gemm(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, stream));
+            TRY(esmk_gemm_ws(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, skp, w.splitk_bytes, stream));
             TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
                                b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
-            TRY(esmk_gemm(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+            TRY(esmk_gemm_ws(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
             pending = dbuf;
         }
         // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
         TRY(esmk_add_layernorm(x, pending, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
         if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
-        TRY(esmk_gemm(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, stream));
+        TRY(esmk_gemm_ws(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, skp, w.splitk_bytes, stream));
         if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
-        TRY(esmk_gemm(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbuf, stream));
+        TRY(esmk_gemm_ws(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
         pending = dbuf;
     }
     // final: fold the last delta into x (pre-norm output) and normalise (transformer_stack.py:94)
@@ -155,9 +162,18 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
     return ESMK_OK;
 }
 
+static size_t head_splitk_bytes(int M, int d) {
+    // out_dim is not known to the size query: 4096 covers the widest head of the path (ESM3 structure head is 4096,
+    // function 2080); wider heads simply run unsplit
+    size_t a = esmk_gemm_workspace_bytes(M, d, d), b = 0;
+    const int outs[] = {64, 11, 19, 1478, 2080, 4096};
+    for (int o : outs) { const size_t x = esmk_gemm_workspace_bytes(M, o, d); if (x > b) b = x; }
+    return a > b ? a : b;
+}
+
 extern "C" size_t esmk_head_workspace_bytes(int n_tokens, int d_model) {
     if (n_tokens <= 0 || d_model <= 0) return 0;
-    return 3 * align256((size_t)n_tokens * d_model * 2);
+    return 3 * align256((size_t)n_tokens * d_model * 2) + align256(head_splitk_bytes(n_tokens, d_model));
 }
 
 extern "C" int esmk_head_forward(const esmk_head* hd, const float* x_norm, float* logits, int M, int d, void* workspace,
@@ -178,9 +194,11 @@ extern "C" int esmk_head_forward(const esmk_head* hd, const float* x_norm, float
     // fp32 -> bf16 cast of the post-norm activations = LayerNorm-free copy: reuse the GEMM input path by
     // running an identity-affine "LayerNorm" is wrong (it would renormalise), so cast with a dedicated pass.
     TRY(esmk_cast_f32_bf16(x_norm, xb, (size_t)M * d, (hipStream_t)stream));
-    TRY(esmk_gemm(xb, d, hd->w0, M, d, d, ESMK_EPI_BIAS_GELU, hd->b0, 1.f, h0, stream));
+    void* skp = ws + 3 * stride;
+    const size_t skb = head_splitk_bytes(M, d);
+    TRY(esmk_gemm_ws(xb, d, hd->w0, M, d, d, ESMK_EPI_BIAS_GELU, hd->b0, 1.f, h0, skp, skb, stream));
     TRY(esmk_layernorm(h0, ESMK_BF16, hd->ln_g, hd->ln_b, h1, ESMK_BF16, M, d, 1e-5f, stream));
-    TRY(esmk_gemm(h1, d, hd->w3, M, hd->out_dim, d, ESMK_EPI_F32, hd->b3, 1.f, logits, stream));
+    TRY(esmk_gemm_ws(h1, d, hd->w3, M, hd->out_dim, d, ESMK_EPI_F32, hd->b3, 1.f, logits, skp, skb, stream));
     return ESMK_OK;
 }
 

@@ -157,8 +157,10 @@ class ESM3(nn.Module):
         ranges = ((sequence_tokens, 64, "sequence_tokens"), (structure_tokens, 4101, "structure_tokens"),
                   (ss8_tokens, 11, "ss8_tokens"), (sasa_tokens, 19, "sasa_tokens"),
                   (function_tokens, 260, "function_tokens"), (residue_annotation_tokens, 1478, "residue_annotation_tokens"))
-        for t, n, name in ranges:
-            if int(t.min()) < 0 or int(t.max()) >= n:
+        # one device->host round trip for all twelve bounds (each int(t.min()) would be a synchronisation of its own)
+        bounds = torch.stack([torch.stack((t.min(), t.max())) for t, _n, _name in ranges]).tolist()
+        for (lo, hi), (_t, n, name) in zip(bounds, ranges):
+            if lo < 0 or hi >= n:
                 raise IndexError(f"{name} out of range [0, {n})")
         M = B * Ln
         x = torch.empty((M, self.d_model), dtype=torch.float32, device=device)

@@ -92,6 +92,14 @@ int esmk_add_layernorm(float* x, const void* delta_bf16, const float* gamma, con
 #define ESMK_EPI_BIAS_GELU 4
 int esmk_gemm(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
               const float* bias, float alpha, void* out, esmk_stream_t stream);
+/* Same operation with a caller-owned scratch buffer: small problems (few output tiles, long K) then split K over
+ * several workgroups per tile - fp32 partials in the workspace, summed in a fixed order (deterministic) by a
+ * second pass that applies the epilogue.  esmk_gemm_workspace_bytes() returns 0 when the shape would not be split;
+ * a NULL / too small workspace falls back to the unsplit kernels (same results up to fp32 summation order). */
+size_t esmk_gemm_workspace_bytes(int M, int N, int K);
+int esmk_gemm_ws(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
+                 const float* bias, float alpha, void* out, void* workspace, size_t workspace_bytes,
+                 esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * QK-LayerNorm + rotary, in place on the packed qkv buffer.

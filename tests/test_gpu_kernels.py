@@ -202,3 +202,52 @@ def test_error_paths_do_not_launch():
     assert rc == -1
     with pytest.raises(L.EsmkError):
         L.check(rc, "esmk_gemm")
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 1536, 4096), (300, 960, 2560), (2048, 960, 960), (512, 70, 1536), (100, 11, 1152)])
+def test_gemm_split_k_all_epilogues(M, N, K):
+    """Small-M shapes take the split-K path when a workspace is lent: every epilogue against torch, equal to the
+    unsplit kernel within fp32 summation-order noise, and bit-identical from run to run (fixed summation order)."""
+    L, lib, engine = _env()
+    need = lib.esmk_gemm_workspace_bytes(M, N, K)
+    assert need > 0, "shape expected to be split"
+    ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = torch.randn(N, K, generator=g) * 0.05
+    Wp = engine.pack_weight(W, "cuda")
+    y = A.float() @ W.bfloat16().float().cuda().T
+    bias = torch.randn(N, generator=g).cuda()
+
+    def run(epi, b, alpha, out, with_ws=True):
+        L.check(lib.esmk_gemm_ws(A.data_ptr(), K, Wp.data_ptr(), M, N, K, epi, None if b is None else b.data_ptr(), alpha,
+                                 out.data_ptr(), ws.data_ptr() if with_ws else None, need if with_ws else 0, _s()))
+        torch.cuda.synchronize()
+        return out
+
+    tol = 0.01 * y.abs().max().item() + 1e-3
+    o1 = run(L.EPI_BF16, None, 0.5, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"))
+    assert (o1.float() - 0.5 * y).abs().max().item() <= tol
+    o1b = run(L.EPI_BF16, None, 0.5, torch.empty((M, N), dtype=torch.bfloat16, device="cuda"))
+    assert torch.equal(o1, o1b)
+    o0 = run(L.EPI_BF16, None, 0.5, torch.empty((M, N), dtype=torch.bfloat16, device="cuda"), with_ws=False)
+    assert (o1.float() - o0.float()).abs().max().item() <= 0.005 * y.abs().max().item() + 1e-3
+    o2 = run(L.EPI_F32, bias, 1.0, torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda"))
+    assert (o2 - (y + bias)).abs().max().item() <= 2e-3 * max(1.0, y.abs().max().item())
+    o3 = run(L.EPI_BIAS_GELU, bias, 1.0, torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda"))
+    ref = torch.nn.functional.gelu(y + bias)
+    assert (o3.float() - ref).abs().max().item() <= 0.01 * ref.abs().max().item() + 1e-3
+    if N % 32 == 0:
+        Wsp = engine.pack_weight(W, "cuda", L.PACK_SWIGLU)
+        o4 = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device="cuda")
+        L.check(lib.esmk_gemm_ws(A.data_ptr(), K, Wsp.data_ptr(), M, N, K, L.EPI_SWIGLU, None, 1.0, o4.data_ptr(),
+                                 ws.data_ptr(), need, _s()))
+        ref = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:]
+        assert (o4.float() - ref).abs().max().item() <= 0.01 * ref.abs().max().item() + 1e-3
+
+
+def test_gemm_split_k_not_for_big_shapes():
+    L, lib, engine = _env()
+    assert lib.esmk_gemm_workspace_bytes(32768, 1152, 3072) == 0
+    assert lib.esmk_gemm_workspace_bytes(512, 8192, 1536) == 0   # 256 tiles: enough workgroups already
+    assert lib.esmk_gemm_workspace_bytes(512, 1536, 256) == 0    # too few K-steps to split
