@@ -65,10 +65,10 @@ def packed_row(lengths, total):
     return row, sid
 
 
-def stack_case(name, d, H, NL, L, wseed):
+def stack_case(name, d, H, NL, L, wseed, scale_residue=True):
     """True-width trunk, few layers: input activations -> (post, pre)."""
     w = synth.make_weights(synth.trunk_shapes("", d, NL), seed=wseed)
-    m = ref_import.build_stack(d, H, NL, w)
+    m = ref_import.build_stack(d, H, NL, w, scale_residue=scale_residue)
     g = torch.Generator().manual_seed(wseed + 17)
     x = torch.randn(2, L, d, generator=g)
     sid = torch.ones(2, L, dtype=torch.bool)
@@ -76,7 +76,7 @@ def stack_case(name, d, H, NL, L, wseed):
     with torch.no_grad():
         post, pre, hid = m(x, sequence_id=sid)
     save(name, kind="stack", d=d, H=H, NL=NL, wseed=wseed, x=_np(x), sequence_id=_np(sid),
-         post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4)
+         post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4, scale_residue=int(scale_residue))
 
 
 def esm3_inputs(B, L, lengths, seed, with_tracks=True):
@@ -298,6 +298,8 @@ def main():
         return text_cases()
     if "--sampling-only" in sys.argv:
         return sampling_cases()
+    if "--vqdec-only" in sys.argv:
+        return stack_case("stack_d1280_vqdec", 1280, 20, 30, 64, wseed=61, scale_residue=False)
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -325,6 +327,8 @@ def main():
     # (ii) true-width trunks, 2 layers, L=64
     for d, H in ((960, 15), (1152, 18), (1536, 24), (2560, 40)):
         stack_case(f"stack_d{d}", d, H, 2, 64, wseed=20 + H)
+    # the VQ-VAE structure decoder's stack: d1280, 20 heads, 30 layers, no residue scaling (vqvae.py:337-339)
+    stack_case("stack_d1280_vqdec", 1280, 20, 30, 64, wseed=61, scale_residue=False)
     # (iii) full-depth ESMC-300M-shaped (C1 geometry), 2 x 128
     esmc_case("esmc_300m_2x128", 960, 15, 30, [128, 101], wseed=31, tseed=300, store_hidden=(0, 14, 29),
               token_stride=2)

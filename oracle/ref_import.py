@@ -87,12 +87,12 @@ def build_esm3(d_model: int, n_heads: int, v_heads: int, n_layers: int, weights:
 
 
 def build_stack(d_model, n_heads, n_layers, weights: dict, v_heads=None, n_layers_geom=0,
-                mask_and_zero_frameless=False):
+                mask_and_zero_frameless=False, scale_residue=True):
     install()
     from esm.layers.transformer_stack import TransformerStack
 
     m = TransformerStack(d_model, n_heads, v_heads, n_layers, n_layers_geom=n_layers_geom,
-                         mask_and_zero_frameless=mask_and_zero_frameless).eval()
+                         mask_and_zero_frameless=mask_and_zero_frameless, scale_residue=scale_residue).eval()
     m.load_state_dict(weights, strict=True)
     return m
 

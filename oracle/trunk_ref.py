@@ -182,11 +182,12 @@ def transformer_block(x, sequence_id, frames, chain_id, w, prefix, n_heads, v_he
 
 
 def transformer_stack(x, sequence_id, w, prefix, n_heads, n_layers, v_heads=None, n_layers_geom=0,
-                      frames=None, chain_id=None):
-    """esm/layers/transformer_stack.py:64-94 -> (post_norm, pre_norm, hiddens)."""
+                      frames=None, chain_id=None, scale_residue=True):
+    """esm/layers/transformer_stack.py:64-94 -> (post_norm, pre_norm, hiddens).  scale_residue=False is the
+    VQ-VAE structure decoder's stack (esm/models/vqvae.py:337-339)."""
     if chain_id is None:
         chain_id = torch.ones(x.shape[:-1], dtype=torch.int64)
-    scale = residue_scale(n_layers)
+    scale = residue_scale(n_layers) if scale_residue else 1.0
     hiddens = []
     for i in range(n_layers):
         x = transformer_block(x, sequence_id, frames, chain_id, w, f"{prefix}blocks.{i}.", n_heads,

@@ -49,12 +49,13 @@ def test_esmc_vs_golden(name):
         assert out.embeddings.cpu()[tok == 1].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560"])
+@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560", "stack_d1280_vqdec"])
 def test_stack_vs_golden(name):
     from esm_amd.transformer_stack import TransformerStack
     fx = G.load(name)
     w = G.weights_for(fx)
-    m = TransformerStack(int(fx["d"]), int(fx["H"]), None, int(fx["NL"]), n_layers_geom=0)
+    m = TransformerStack(int(fx["d"]), int(fx["H"]), None, int(fx["NL"]), n_layers_geom=0,
+                         scale_residue=bool(int(fx["scale_residue"])) if "scale_residue" in fx else True)
     m.load_state_dict(w)
     m = m.cuda()
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None

@@ -30,12 +30,13 @@ def test_esmc(name):
     _close(out["hidden_states"][hl][:, :, ::s][:, valid], G.t(fx["hidden_states"])[:, valid])
 
 
-@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560"])
+@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560", "stack_d1280_vqdec"])
 def test_stack(name):
     fx = G.load(name)
     w = G.weights_for(fx)
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
-    post, pre, _ = trunk_ref.transformer_stack(G.t(fx["x"]), sid, w, "", int(fx["H"]), int(fx["NL"]))
+    post, pre, _ = trunk_ref.transformer_stack(G.t(fx["x"]), sid, w, "", int(fx["H"]), int(fx["NL"]),
+                                               scale_residue=bool(int(fx["scale_residue"])) if "scale_residue" in fx else True)
     s = int(fx["token_stride"])
     valid = sid[:, ::s] if sid is not None else torch.ones(post[:, ::s].shape[:2], dtype=torch.bool)
     _close(post[:, ::s][valid], G.t(fx["post"])[valid])
