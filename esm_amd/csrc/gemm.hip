@@ -268,6 +268,7 @@ int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, co
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                  float alpha, void* out, hipStream_t s, int n_ctile);
+int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s);
 
@@ -329,6 +330,12 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         // measured crossover (tools/gemm_bench.py, M = 512 ... 32768): the 256-tile kernel wins once there are
         // about half as many 256x256 tiles as CUs; below that the 128-tile kernel fills the chip better.
         const bool big = (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
+        // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
+        static int use288 = -1;
+        if (use288 < 0) { const char* e5 = getenv("ESMK_GEMM_288"); use288 = e5 ? atoi(e5) : 1; }
+        if (use288 && ov == 0 && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
+            (long long)((M + 255) / 256) * (N / 288) >= 128)
+            return esmk_gemm288(A, lda, W, M, N, K, alpha, out, s);
         if (ov == 256 || (ov == 0 && big)) {
             // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
             // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call

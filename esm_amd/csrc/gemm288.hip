@@ -1,0 +1,270 @@
+// 288(channel) x 256(token) x 64 bf16 MFMA GEMM for output widths that are multiples of 288 but not of 256
+// (d_model = 1152: N = 1152 = 4 x 288 and 3 x 1152 = 12 x 288).  With 256-wide channel tiles those shapes waste a
+// half-empty tile column and a partial round of workgroups (out-proj / FFN2: 640 tiles = 2.5 rounds of 256 CUs;
+// here 512 tiles = 2 rounds; QKV: 14 columns -> 12).  bf16 output, out = alpha * A.W^T (ESMK_EPI_BF16) only.
+//
+// Same structure as gemm256.hip (read that file first): 8 waves = 2 (channel halves, 144 rows) x 4 (token
+// quarters, 64 rows); LDS-DMA 1.5 K-tiles ahead with counted vmcnt; LDS fragment reads software-pipelined inside
+// each wave; two workgroup barriers per K-tile.  A wave's 144 channels are THREE row groups qm of 48 (3 MFMA rows),
+// so a K-tile is six blocks (qm, kk) of 12 MFMAs.
+//
+// LDS: 2 K-tile buffers x 68 KiB = [UB0 16K | UB1 16K | UA0 12K | UA1 12K | UA2 12K], 128-byte rows, 16-byte chunk
+// XOR-swizzled by (row>>1)&7.  UBq = token rows of quadrant column qn (all wn), UAq = channel rows of group qm (both
+// wm).  The DMA moves the P region [UB0|UB1|UA0] (44 pieces of 1 KiB) and the Q region [UA1|UA2] (24 pieces):
+// wave w owns P pieces w, w+8, ... (6 for waves 0-3, 5 for waves 4-7: template HI) and Q pieces w, w+8, w+16.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "gemm_epi.hpp"
+
+namespace {
+
+constexpr int TC = 288, TT = 256, BK = 64;
+constexpr int UB = 128 * 128, UA = 96 * 128;
+constexpr int OFF_UB0 = 0, OFF_UB1 = UB, OFF_UA0 = 2 * UB, OFF_UA1 = 2 * UB + UA, OFF_UA2 = 2 * UB + 2 * UA;
+constexpr int KBUF = 2 * UB + 3 * UA;                 // 69632 B
+constexpr int PITCH = 144 * 2 + 16;                   // epilogue staging row pitch
+constexpr int LDS_BYTES = 8 * 64 * PITCH;             // 155648 B >= 2 * KBUF
+
+#define SEG_BARRIER()                        \
+    do {                                     \
+        __builtin_amdgcn_sched_barrier(0);   \
+        __builtin_amdgcn_s_barrier();        \
+        __builtin_amdgcn_sched_barrier(0);   \
+    } while (0)
+
+template <bool HI>  // HI: waves 0-3 (six P pieces per K-tile), else five
+__device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ W, int ldw,
+                                             int M, int N, int ktiles, float alpha, __bf16* __restrict__ out, int c0,
+                                             int t0, char* smem) {
+    constexpr int NP = HI ? 6 : 5, NQ = 3;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    // ---- DMA sources.  Piece p of a region covers its rows 8p..8p+7; this lane moves row 8p + (lane>>3),
+    //      logical chunk (lane&7) ^ swizzle(row).  P region: pieces 0..31 are token rows (UB0, UB1), 32..43 UA0. ----
+    const char* wbase = (const char*)(W + (size_t)c0 * ldw);
+    const char* abase = (const char*)(A + (size_t)t0 * lda);
+    auto a_row_off = [&](int unit_row, int qm) {  // channel row of UA[qm] -> byte offset from wbase
+        const int w2 = unit_row / 48, rem = unit_row - w2 * 48;
+        return (unsigned)(w2 * 144 + qm * 48 + rem) * (unsigned)(ldw * 2);
+    };
+    auto b_row_off = [&](int unit_row, int qn) {  // token row of UB[qn] -> byte offset from abase (clamped to M-1)
+        int tr = (unit_row >> 5) * 64 + qn * 32 + (unit_row & 31);
+        tr = t0 + tr < M ? tr : M - 1 - t0;
+        return (unsigned)tr * (unsigned)(lda * 2);
+    };
+    unsigned soffP[6], soffQ[3];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int p = wave + 8 * j;                       // piece inside the P region
+        const int r8 = lane >> 3;
+        if (j < 4) {                                      // UB0 (j = 0,1) / UB1 (j = 2,3)
+            const int ur = (p & 15) * 8 + r8;
+            soffP[j] = b_row_off(ur, j >> 1) + (((lane & 7) ^ ((ur >> 1) & 7)) << 4);
+        } else {                                          // UA0: pieces 32..43
+            const int ur = (p - 32) * 8 + r8;             // < 96 for the pieces that exist (HI: j = 5 -> p = 40..43)
+            soffP[j] = a_row_off(ur < 96 ? ur : 95, 0) + (((lane & 7) ^ ((ur >> 1) & 7)) << 4);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int p = wave + 8 * j;                       // 0..23: UA1 = 0..11, UA2 = 12..23
+        const int qm = p < 12 ? 1 : 2;
+        const int ur = (p - (qm - 1) * 12) * 8 + (lane >> 3);
+        soffQ[j] = a_row_off(ur, qm) + (((lane & 7) ^ ((ur >> 1) & 7)) << 4);
+    }
+    auto issue_P = [&](int j, int kt) {  // j compile-time after unrolling
+        char* dst = smem + (kt & 1) * KBUF + (wave + 8 * j) * 1024;
+        const char* base = (j < 4 ? abase : wbase) + (size_t)kt * (BK * 2);
+        __builtin_amdgcn_global_load_lds(GLB_PTR(base + soffP[j]), LDS_PTR(dst), 16, 0, 0);
+    };
+    auto issue_Q = [&](int j, int kt) {
+        char* dst = smem + (kt & 1) * KBUF + OFF_UA1 + (wave + 8 * j) * 1024;
+        __builtin_amdgcn_global_load_lds(GLB_PTR(wbase + (size_t)kt * (BK * 2) + soffQ[j]), LDS_PTR(dst), 16, 0, 0);
+    };
+    auto issue_tile = [&](int kt) {
+#pragma unroll
+        for (int j = 0; j < NP; ++j) issue_P(j, kt);
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) issue_Q(j, kt);
+    };
+
+    // ---- fragment read offsets inside a unit (kk = 0, mi / ni = 0) ----
+    const int ra = wm * 48 + (lane & 15), rb = wn * 32 + (lane & 15);
+    const int a_off = ra * 128 + (((lane >> 4) ^ ((ra >> 1) & 7)) << 4);
+    const int b_off = rb * 128 + (((lane >> 4) ^ ((rb >> 1) & 7)) << 4);
+
+    f32x4 acc[3][2][3][2];  // [qm][qn][mi][ni]
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[3][2], bfr[2][2][2];  // A rows of the current qm; B rows of both qn
+
+    auto read_a_kk = [&](const char* unit, int kk) {
+#pragma unroll
+        for (int mi = 0; mi < 3; ++mi) af[mi][kk] = *(const bf16x8*)(unit + ((a_off + mi * 2048) ^ (kk << 6)));
+    };
+    auto read_b_kk = [&](const char* buf, int kk) {
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                bfr[qn][ni][kk] = *(const bf16x8*)(buf + qn * UB + ((b_off + ni * 2048) ^ (kk << 6)));
+    };
+
+    // ---- prologue: tiles 0 and 1 in flight; wait for P(0) ----
+    issue_tile(0);
+    if (ktiles > 1) {
+        issue_tile(1);
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ + NP) : "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
+    }
+    SEG_BARRIER();
+    read_a_kk(smem + OFF_UA0, 0);
+    read_b_kk(smem, 0);
+
+#define MF(QM, KK, QN, MI, NI)                                                                     \
+    acc[QM][QN][MI][NI] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[MI][KK], bfr[QN][NI][KK], acc[QM][QN][MI][NI], 0, 0, 0);
+#define MFPAIR(QM, KK, QN, MI, S)                                                                  \
+    MF(QM, KK, QN, MI, 0) MF(QM, KK, QN, MI, 1)                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    S;                                                                                             \
+    __builtin_amdgcn_sched_barrier(0);
+#define MFMA_BLOCK(QM, KK, S0, S1, S2, S3, S4, S5)                                                 \
+    __builtin_amdgcn_s_setprio(1);                                                                 \
+    MFPAIR(QM, KK, 0, 0, S0) MFPAIR(QM, KK, 0, 1, S1) MFPAIR(QM, KK, 0, 2, S2)                     \
+    MFPAIR(QM, KK, 1, 0, S3) MFPAIR(QM, KK, 1, 1, S4) MFPAIR(QM, KK, 1, 2, S5)                     \
+    __builtin_amdgcn_s_setprio(0);
+#define NOP_ ((void)0)
+
+    // Six blocks per K-tile; every block issues the LDS reads of the fragments the NEXT block consumes:
+    //   B1 (qm0,kk0): reads kk1 of UA0 + UB            then vmcnt / lgkmcnt(0) / barrier P
+    //   B2 (qm0,kk1): reads kk0 of UA1; DMA P pieces 0-4 of tile kt+2 (the P region of this buffer is free)
+    //   B3 (qm1,kk0): reads kk1 of UA1; DMA P piece 5 (waves 0-3)
+    //   B4 (qm1,kk1): reads kk0 of UA2
+    //   B5 (qm2,kk0): reads kk1 of UA2                 then vmcnt / lgkmcnt(0) / barrier Q
+    //   B6 (qm2,kk1): reads kk0 of UA0 + UB of tile kt+1; DMA Q pieces of tile kt+2
+    // Barrier P(kt): Q(kt) (UA1, UA2) has landed for every wave; all waves are done with the P region of this buffer.
+    // Barrier Q(kt): P(kt+1) has landed; all waves are done with UA1 / UA2 of this buffer.
+    // Issue order per wave: P(t), Q(t), P(t+1), Q(t+1), ...  =>  "all but the two youngest groups" = vmcnt(NP + NQ).
+#define KTILE(M1, M2)                                                                              \
+    {                                                                                              \
+        const char* cur = smem + (kt & 1) * KBUF;                                                  \
+        const char* nxt = smem + ((kt + 1) & 1) * KBUF;                                            \
+        MFMA_BLOCK(0, 0, { read_a_kk(cur + OFF_UA0, 1); read_b_kk(cur, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_) \
+        if (M1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NQ) : "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        SEG_BARRIER();                                                                             \
+        MFMA_BLOCK(0, 1, { read_a_kk(cur + OFF_UA1, 0); }, { if (M2) issue_P(0, kt + 2); },        \
+                   { if (M2) issue_P(1, kt + 2); }, { if (M2) issue_P(2, kt + 2); },               \
+                   { if (M2) issue_P(3, kt + 2); }, { if (M2) issue_P(4, kt + 2); })               \
+        MFMA_BLOCK(1, 0, { read_a_kk(cur + OFF_UA1, 1); }, { if (M2 && HI) issue_P(5, kt + 2); }, NOP_, NOP_, NOP_, NOP_) \
+        MFMA_BLOCK(1, 1, { read_a_kk(cur + OFF_UA2, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        MFMA_BLOCK(2, 0, { read_a_kk(cur + OFF_UA2, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        if (M2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NQ) : "memory");                     \
+        else if (M1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        SEG_BARRIER();                                                                             \
+        MFMA_BLOCK(2, 1, { if (M1) { read_a_kk(nxt + OFF_UA0, 0); read_b_kk(nxt, 0); } },          \
+                   { if (M2) issue_Q(0, kt + 2); }, { if (M2) issue_Q(1, kt + 2); },               \
+                   { if (M2) issue_Q(2, kt + 2); }, NOP_, NOP_)                                    \
+    }
+
+    int kt = 0;
+    for (; kt < ktiles - 2; ++kt) KTILE(true, true)
+    if (ktiles >= 2) {
+        KTILE(true, false)
+        ++kt;
+    }
+    KTILE(false, false)
+#undef KTILE
+#undef MFMA_BLOCK
+#undef MFPAIR
+#undef MF
+#undef NOP_
+
+    // ---- epilogue: stage this wave's 64 tokens x 144 channels through its own LDS region (no wave reads
+    //      fragments after barrier Q of the last tile) and store whole 288-byte row pieces, 16 B per lane ----
+    const int q4 = (lane >> 4) * 4;
+    char* stg = smem + wave * (64 * PITCH);
+#pragma unroll
+    for (int qm = 0; qm < 3; ++qm)
+#pragma unroll
+        for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int trow = qn * 32 + ni * 16 + (lane & 15);
+#pragma unroll
+                for (int mi = 0; mi < 3; ++mi) {
+                    const f32x4 v = acc[qm][qn][mi][ni] * alpha;
+                    u32x2 pk;
+                    pk.x = pack_bf16x2(v[0], v[1]);
+                    pk.y = pack_bf16x2(v[2], v[3]);
+                    *(u32x2*)(stg + trow * PITCH + (qm * 48 + mi * 16 + q4) * 2) = pk;
+                }
+            }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    // 18 lanes cover one 288-byte row: 3 rows per wave instruction (lanes 0..53)
+    const int lr = lane / 18, lc = lane - lr * 18;
+    const int cc = c0 + wm * 144 + lc * 8;
+#pragma unroll
+    for (int it = 0; it < 22; ++it) {
+        const int trow = it * 3 + lr;
+        const int t = t0 + wn * 64 + trow;
+        if (lane < 54 && trow < 64 && t < M) {
+            const u32x4 v = *(const u32x4*)(stg + trow * PITCH + lc * 16);
+            *(u32x4*)(out + (size_t)t * N + cc) = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(512, 2) void gemm288_kernel(const __bf16* __restrict__ A, int lda,
+                                                         const __bf16* __restrict__ W, int ldw, int M, int N,
+                                                         int ktiles, float alpha, __bf16* __restrict__ out,
+                                                         int n_ctile, int nblk, int gt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // tile order: see gemm256.hip (XCD-contiguous id ranges, panels of gt token tiles x all channel tiles)
+    const int id = xcd_remap(blockIdx.x, nblk);
+    const int n_ttile = nblk / n_ctile;
+    const int panel = id / (gt * n_ctile);
+    const int gtp = min(gt, n_ttile - panel * gt);
+    const int idp = id - panel * gt * n_ctile;
+    const int ctile = idp / gtp, ttile = panel * gt + (idp - ctile * gtp);
+    const int c0 = ctile * TC, t0 = ttile * TT;
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4)
+        gemm288_body<true>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+    else
+        gemm288_body<false>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+}
+
+}  // namespace
+
+// Called by esmk_gemm (gemm.hip): N % 288 == 0, bf16 output.  W packed with rows padded to 256 (>= N rows exist).
+int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+    const int Kpad = round_up(K, BK);
+    const int n_ctile = N / TC;
+    const int n_ttile = (M + TT - 1) / TT;
+    const int nblk = n_ctile * n_ttile;
+    static int gt = 0;
+    if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void*)gemm288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", LDS_BYTES);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(gemm288_kernel, dim3(nblk), dim3(512), LDS_BYTES, s, (const __bf16*)A, lda, (const __bf16*)W, Kpad,
+                       M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt);
+    ESMK_CHECK_LAUNCH("esmk_gemm(288)");
+    return ESMK_OK;
+}

@@ -251,3 +251,22 @@ def test_gemm_split_k_not_for_big_shapes():
     assert lib.esmk_gemm_workspace_bytes(32768, 1152, 3072) == 0
     assert lib.esmk_gemm_workspace_bytes(512, 8192, 1536) == 0   # 256 tiles: enough workgroups already
     assert lib.esmk_gemm_workspace_bytes(512, 1536, 256) == 0    # too few K-steps to split
+
+
+@pytest.mark.parametrize("M,N,K", [(8192, 1152, 64), (8200, 1152, 128), (9000, 3456, 192), (20000, 1152, 3072),
+                                   (32768, 3456, 1152)])
+def test_gemm_288_channel_tiles(M, N, K):
+    """Widths that are multiples of 288 but not 256 take the 288x256 kernel (1, 2, 3, 48, 18 K-tiles; ragged M)."""
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = torch.randn(N, K, generator=g) * 0.05
+    Wp = engine.pack_weight(W, "cuda")
+    ref = 0.5 * (A.float() @ W.bfloat16().float().cuda().T)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for _ in range(2):
+        L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_BF16, None, 0.5, out.data_ptr(), _s()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
