@@ -54,6 +54,7 @@ SIGNATURES = {
     "esmk_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_layernorm": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "esmk_add_layernorm": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
+    "esmk_add2_layernorm": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
     "esmk_gemm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_gemm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "esmk_gemm_ws": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_size_t, vp]),

@@ -36,11 +36,14 @@ __device__ __forceinline__ f32x4 ln_cvt(const u32x2 p) {
                  __uint_as_float(p.y & 0xffff0000u)};
 }
 
-// ADD: x (f32, in/out) += delta (bf16) before normalising; the updated row is written back to x.
-template <typename TIN, typename TOUT, bool ADD, int NV>
+// ADD: 0 = plain LayerNorm; 1 = x (f32, in/out) += delta (bf16) first, updated row written back;
+//      2 = normalise x + delta but leave x alone (the delta stays pending for the next pass);
+//      3 = x += delta + delta2, written back.  The sum is always formed as (x + delta) + delta2.
+template <typename TIN, typename TOUT, int ADD, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOUT* __restrict__ y, int M,
-                                                        int d, int ldy, float eps, const __bf16* __restrict__ delta) {
+                                                        int d, int ldy, float eps, const __bf16* __restrict__ delta,
+                                                        const __bf16* __restrict__ delta2) {
     extern __shared__ __attribute__((aligned(16))) float gb[];  // gamma[d] | beta[d]
     using RAW = typename LnRaw<TIN>::type;
     const int lane = threadIdx.x & 63;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
     const int stride = gridDim.x * 4;
     int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     RAW xr[NV];
-    u32x2 dr[NV];
+    u32x2 dr[NV], dr2[NV];
     auto load_row = [&](int r) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
@@ -61,7 +64,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
             if (c < nvec) {
                 // streamed once: x is next touched a whole sub-block later, delta never again
                 xr[i] = __builtin_nontemporal_load((const RAW*)(x + (size_t)r * d + c * 4));
-                if constexpr (ADD) dr[i] = __builtin_nontemporal_load((const u32x2*)(delta + (size_t)r * d + c * 4));
+                if constexpr (ADD != 0) dr[i] = __builtin_nontemporal_load((const u32x2*)(delta + (size_t)r * d + c * 4));
+                if constexpr (ADD == 3) dr2[i] = __builtin_nontemporal_load((const u32x2*)(delta2 + (size_t)r * d + c * 4));
             }
         }
     };
@@ -75,10 +79,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
             v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (c < nvec) {
                 v[i] = ln_cvt(xr[i]);
-                if constexpr (ADD) {
-                    v[i] += ln_cvt(dr[i]);
+                if constexpr (ADD != 0) v[i] += ln_cvt(dr[i]);
+                if constexpr (ADD == 3) v[i] += ln_cvt(dr2[i]);
+                if constexpr (ADD == 1 || ADD == 3)
                     __builtin_nontemporal_store(v[i], (f32x4*)((float*)x + (size_t)row * d + c * 4));
-                }
                 sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
     }
 }
 
-template <typename TIN, typename TOUT, bool ADD>
+template <typename TIN, typename TOUT, int ADD>
 void launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int d, float eps,
-                      const void* delta, hipStream_t s) {
+                      const void* delta, hipStream_t s, const void* delta2 = nullptr) {
     const int nv = (d / 4 + 63) / 64;
     const size_t lds = (size_t)2 * d * sizeof(float);
 #define LN_LAUNCH(NV)                                                                                                \
@@ -122,7 +126,8 @@ void launch_layernorm(const void* x, const float* gamma, const float* beta, void
         static int cap = 0; /* resident blocks on the device; measured flat from 2 to 5 per CU, use at most 4 */    \
         if (cap == 0) cap = persistent_blocks(layernorm_kernel<TIN, TOUT, ADD, NV>, lds, 1 << 30, 4);                \
         hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, ADD, NV>), dim3(min((M + 3) / 4, cap)), dim3(256), lds, s,   \
-                           (const TIN*)x, gamma, beta, (TOUT*)y, M, d, d, eps, (const __bf16*)delta);                \
+                           (const TIN*)x, gamma, beta, (TOUT*)y, M, d, d, eps, (const __bf16*)delta,                 \
+                           (const __bf16*)delta2);                                                                   \
     } while (0)
     if (nv <= 2) LN_LAUNCH(2);
     else if (nv <= 4) LN_LAUNCH(4);
@@ -353,13 +358,13 @@ extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, co
     if (M == 0) return ESMK_OK;
     hipStream_t s = (hipStream_t)stream;
     if (x_dtype == ESMK_F32 && y_dtype == ESMK_BF16)
-        launch_layernorm<float, __bf16, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
+        launch_layernorm<float, __bf16, 0>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_F32 && y_dtype == ESMK_F32)
-        launch_layernorm<float, float, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
+        launch_layernorm<float, float, 0>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_BF16 && y_dtype == ESMK_BF16)
-        launch_layernorm<__bf16, __bf16, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
+        launch_layernorm<__bf16, __bf16, 0>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else if (x_dtype == ESMK_BF16 && y_dtype == ESMK_F32)
-        launch_layernorm<__bf16, float, false>(x, gamma, beta, y, M, d, eps, nullptr, s);
+        launch_layernorm<__bf16, float, 0>(x, gamma, beta, y, M, d, eps, nullptr, s);
     else
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_layernorm: bad dtype");
     ESMK_CHECK_LAUNCH("esmk_layernorm");
@@ -376,12 +381,35 @@ extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamm
     if (M == 0) return ESMK_OK;
     hipStream_t s = (hipStream_t)stream;
     if (y_dtype == ESMK_BF16)
-        launch_layernorm<float, __bf16, true>(x, gamma, beta, y, M, d, eps, delta, s);
+        launch_layernorm<float, __bf16, 1>(x, gamma, beta, y, M, d, eps, delta, s);
     else if (y_dtype == ESMK_F32)
-        launch_layernorm<float, float, true>(x, gamma, beta, y, M, d, eps, delta, s);
+        launch_layernorm<float, float, 1>(x, gamma, beta, y, M, d, eps, delta, s);
     else
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add_layernorm: bad dtype");
     ESMK_CHECK_LAUNCH("esmk_add_layernorm");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_add2_layernorm(float* x, const void* delta_a, const void* delta_b, int write_x, const float* gamma,
+                                   const float* beta, void* y, int y_dtype, int M, int d, float eps,
+                                   esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (!delta_b && write_x) return esmk_add_layernorm(x, delta_a, gamma, beta, y, y_dtype, M, d, eps, stream);
+    if (!x || !delta_a || !gamma || !y) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add2_layernorm: null pointer");
+    if (delta_b && !write_x) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_add2_layernorm: two deltas must be written back");
+    if (M < 0 || d <= 0 || (d & 3) || d > LN_MAX_VEC * 256)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_add2_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == ESMK_BF16) {
+        if (delta_b) launch_layernorm<float, __bf16, 3>(x, gamma, beta, y, M, d, eps, delta_a, s, delta_b);
+        else launch_layernorm<float, __bf16, 2>(x, gamma, beta, y, M, d, eps, delta_a, s);
+    } else if (y_dtype == ESMK_F32) {
+        if (delta_b) launch_layernorm<float, float, 3>(x, gamma, beta, y, M, d, eps, delta_a, s, delta_b);
+        else launch_layernorm<float, float, 2>(x, gamma, beta, y, M, d, eps, delta_a, s);
+    } else {
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add2_layernorm: bad dtype");
+    }
+    ESMK_CHECK_LAUNCH("esmk_add2_layernorm");
     return ESMK_OK;
 }
 

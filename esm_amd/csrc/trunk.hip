@@ -26,7 +26,7 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TrunkWs {
-    size_t xn, qkv, ctx, hbuf, dbuf, gproj, gout, gscratch, splitk, splitk_bytes, total;
+    size_t xn, qkv, ctx, hbuf, dbuf, dbuf2, gproj, gout, gscratch, splitk, splitk_bytes, total;
 };
 
 TrunkWs trunk_layout(const esmk_trunk* t, int M) {
@@ -38,6 +38,7 @@ TrunkWs trunk_layout(const esmk_trunk* t, int M) {
     w.ctx = off;  off += align256((size_t)M * d * 2);
     w.hbuf = off; off += align256((size_t)M * h * 2);
     w.dbuf = off; off += align256((size_t)M * d * 2);
+    w.dbuf2 = off; off += align256((size_t)M * d * 2);
     bool geom = false;
     for (int i = 0; i < t->n_layers; ++i) geom = geom || (t->layers[i].geom_ln_g != nullptr);
     if (geom) {
@@ -107,17 +108,29 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
     hipStream_t s = (hipStream_t)stream;
 
     // Residual updates travel as bf16 deltas (already scaled by 1/s in the producing GEMM's epilogue) and are
-    // folded into the fp32 stream by the NEXT LayerNorm pass (esmk_add_layernorm): x is read and written once
-    // per sub-block instead of twice, and every big GEMM ends in a coalesced bf16 store.
-    void* dbuf = ws + w.dbuf;
+    // folded into the fp32 stream by a later LayerNorm pass, so every big GEMM ends in a coalesced bf16 store.
+    // Up to two deltas stay pending: the pass in front of the FFN normalises x + delta_attn WITHOUT writing x,
+    // and the first pass of the next block adds delta_attn and delta_ffn in one go - the fp32 stream is written
+    // once per block.  Sums are always formed as (x + delta_a) + delta_b: same values as adding one at a time.
+    void* dbufA = ws + w.dbuf2;  // attention / geometric deltas
+    void* dbufF = ws + w.dbuf;   // FFN deltas
     void* skp = w.splitk_bytes ? (void*)(ws + w.splitk) : nullptr;
-    const void* pending = nullptr;  // delta not yet added to x
+    const void* pa = nullptr;    // pending deltas, oldest first
+    const void* pb = nullptr;
+    // x = x + pending deltas (written back), y = LN(x)
+    auto flush_ln = [&](const float* g, const float* be, void* y, int ydt) -> int {
+        int rc;
+        if (pa && pb) rc = esmk_add2_layernorm(x, pa, pb, 1, g, be, y, ydt, M, d, eps, stream);
+        else rc = esmk_add_layernorm(x, pa, g, be, y, ydt, M, d, eps, stream);  // pa may be NULL: plain LayerNorm
+        pa = pb = nullptr;
+        return rc;
+    };
     for (int i = 0; i < t->n_layers; ++i) {
         const esmk_layer& L = t->layers[i];
         if (!L.ln1_g || !L.ln1_b || !L.w_qkv || !L.qln_g || !L.kln_g || !L.w_o || !L.ln2_g || !L.ln2_b || !L.w_ffn1 || !L.w_ffn2)
             ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
         // --- x += MHA(x) / s  (attention.py:48-82, blocks.py:146-148)
-        TRY(esmk_add_layernorm(x, pending, L.ln1_g, L.ln1_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(flush_ln(L.ln1_g, L.ln1_b, xn, ESMK_BF16));
         if (hiddens && i > 0) {  // x now holds block i-1's output
             if (hipMemcpyAsync(hiddens + (size_t)(i - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
                 ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
@@ -125,8 +138,8 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
         TRY(esmk_gemm_ws(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, skp, w.splitk_bytes, stream));
         TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
         TRY(esmk_attn_varlen(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, stream));
-        TRY(esmk_gemm_ws(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
-        pending = dbuf;
+        TRY(esmk_gemm_ws(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbufA, skp, w.splitk_bytes, stream));
+        pa = dbufA;
         // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)
         if (L.geom_ln_g) {
             const int vh = t->v_heads;
@@ -137,24 +150,24 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
             float* gproj = (float*)(ws + w.gproj);
             void* gout = ws + w.gout;
             const int ldg = round_up(3 * vh, 64);
-            TRY(esmk_add_layernorm(x, pending, L.geom_ln_g, nullptr, xn, ESMK_BF16, M, d, eps, stream));
+            TRY(flush_ln(L.geom_ln_g, nullptr, xn, ESMK_BF16));  // dbufA is free again after this pass
             TRY(esmk_gemm_ws(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, skp, w.splitk_bytes, stream));
             TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
                                b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
-            TRY(esmk_gemm_ws(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
-            pending = dbuf;
+            TRY(esmk_gemm_ws(gout, ldg, L.w_geom_out, M, d, 3 * vh, ESMK_EPI_BF16, nullptr, inv_s, dbufA, skp, w.splitk_bytes, stream));
+            pa = dbufA;
         }
         // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
-        TRY(esmk_add_layernorm(x, pending, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));
+        TRY(esmk_add2_layernorm(x, pa, nullptr, 0, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));  // x untouched
         if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
         TRY(esmk_gemm_ws(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, skp, w.splitk_bytes, stream));
         if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
-        TRY(esmk_gemm_ws(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbuf, skp, w.splitk_bytes, stream));
-        pending = dbuf;
+        TRY(esmk_gemm_ws(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbufF, skp, w.splitk_bytes, stream));
+        pb = dbufF;
     }
     // final: fold the last delta into x (pre-norm output) and normalise (transformer_stack.py:94)
     void* post = post_norm ? (void*)post_norm : xn;
-    TRY(esmk_add_layernorm(x, pending, t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16, M, d, eps, stream));
+    TRY(flush_ln(t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16));
     if (hiddens) {
         if (hipMemcpyAsync(hiddens + (size_t)(t->n_layers - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");

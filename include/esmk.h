@@ -72,6 +72,12 @@ int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* 
  * (attention.py:26, blocks.py:31, geom_attention.py:65, transformer_stack.py:94).  delta == NULL: plain LN. */
 int esmk_add_layernorm(float* x, const void* delta_bf16, const float* gamma, const float* beta, void* y,
                        int y_dtype, int M, int d, float eps, esmk_stream_t stream);
+/* Two-delta form used by the trunk to touch the fp32 stream once per block instead of twice:
+ *   write_x = 0, delta_b = NULL : y = LN(x + delta_a), x untouched (delta_a stays pending)
+ *   write_x = 1                 : x = (x + delta_a) + delta_b (delta_b may be NULL), y = LN(x)
+ * Same sums in the same order as two esmk_add_layernorm calls => bit-identical results. */
+int esmk_add2_layernorm(float* x, const void* delta_a_bf16, const void* delta_b_bf16, int write_x, const float* gamma,
+                        const float* beta, void* y, int y_dtype, int M, int d, float eps, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GEMM  out = epilogue(A[M,K] . W[N,K]^T)  on bf16 MFMA with fp32 accumulation.

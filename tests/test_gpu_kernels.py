@@ -270,3 +270,29 @@ def test_gemm_288_channel_tiles(M, N, K):
     assert torch.isfinite(out.float()).all()
     err = (out.float() - ref).abs().max().item()
     assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
+
+
+def test_add2_layernorm_modes():
+    """Two-delta LayerNorm: no-write mode leaves x alone; the two-delta write mode equals two single adds bit for bit."""
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(5)
+    M, d = 300, 1152
+    x0 = torch.randn(M, d, generator=g).cuda()
+    da = (torch.randn(M, d, generator=g) * 0.3).bfloat16().cuda()
+    db = (torch.randn(M, d, generator=g) * 0.3).bfloat16().cuda()
+    gam, bet = torch.randn(d, generator=g).cuda(), torch.randn(d, generator=g).cuda()
+    y = torch.empty(M, d, dtype=torch.bfloat16, device="cuda")
+    x = x0.clone()
+    L.check(lib.esmk_add2_layernorm(x.data_ptr(), da.data_ptr(), None, 0, gam.data_ptr(), bet.data_ptr(), y.data_ptr(), L.BF16, M, d, 1e-5, _s()))
+    assert torch.equal(x, x0)
+    ref = torch.nn.functional.layer_norm(x0 + da.float(), (d,), gam, bet)
+    assert (y.float() - ref).abs().max().item() <= 0.02 * ref.abs().max().item()
+    # one pass with two deltas == two passes with one delta each
+    y2 = torch.empty(M, d, dtype=torch.float32, device="cuda")
+    L.check(lib.esmk_add2_layernorm(x.data_ptr(), da.data_ptr(), db.data_ptr(), 1, gam.data_ptr(), None, y2.data_ptr(), L.F32, M, d, 1e-5, _s()))
+    xs = x0.clone()
+    tmp = torch.empty(M, d, dtype=torch.float32, device="cuda")
+    L.check(lib.esmk_add_layernorm(xs.data_ptr(), da.data_ptr(), gam.data_ptr(), None, tmp.data_ptr(), L.F32, M, d, 1e-5, _s()))
+    L.check(lib.esmk_add_layernorm(xs.data_ptr(), db.data_ptr(), gam.data_ptr(), None, tmp.data_ptr(), L.F32, M, d, 1e-5, _s()))
+    assert torch.equal(x, xs) and torch.equal(y2, tmp)
+    assert torch.equal(x, (x0 + da.float()) + db.float())
