@@ -119,3 +119,17 @@ class LogitsOutput:
     residue_annotation_logits: torch.Tensor | None = None
     hidden_states: torch.Tensor | None = None
     mean_hidden_state: torch.Tensor | None = None
+
+
+@dataclass
+class ForwardAndSampleOutput(LogitsOutput):
+    """esm/sdk/api.py:414-428."""
+    protein_tensor: ESMProteinTensor | None = None
+    entropy: ForwardTrackData | None = None
+    prob: ForwardTrackData | None = None
+    logprob: ForwardTrackData | None = None
+    top_prob: ForwardTrackData | None = None
+    topk_logprob: ForwardTrackData | None = None
+    topk_tokens: ForwardTrackData | None = None
+    per_residue_embedding: torch.Tensor | None = None
+    mean_embedding: torch.Tensor | None = None

@@ -274,3 +274,70 @@ class ESM3(nn.Module):
             setattr(q, track, done[i, :lens[i]].clone())
             outs.append(q)
         return outs
+
+    def forward_and_sample(self, input: ESMProteinTensor, sampling_configuration, generator=None):
+        """One forward + one sampling step per configured track (reference esm3.py:561-599 with
+        utils/generation.py:553-700): integer tracks through the fused kernel, SASA decoded to floats.
+        Tracks missing from `input` start fully masked (ESMProteinTensor.empty, api.py:251-278)."""
+        import warnings
+        from .api import ForwardAndSampleOutput
+        from .sampling import MAX_TOPK, default_track_tokenizers, sample_sasa_logits, sample_track
+        cfg = sampling_configuration
+        if cfg.function is not None:
+            raise NotImplementedError("function sampling needs the InterPro tokenizer's data files")
+        for name in ("sequence", "structure", "secondary_structure", "sasa"):
+            tc = getattr(cfg, name)
+            if tc is not None and tc.topk_logprobs > MAX_TOPK:  # validate_sampling_config(on_invalid="warn")
+                warnings.warn(f"Sampling track {name} has topk_logprobs={tc.topk_logprobs} greater than MAX_TOPK={MAX_TOPK}.")
+        Ln = len(input)
+        if Ln <= 0:
+            raise ValueError("No input data provided")
+        dev = self.device
+        toks = default_track_tokenizers()
+        tracks = {}
+        for name, (bos, eos, _pad, mask) in self._TRACK_IDS.items():
+            t = getattr(input, name)
+            if t is None:
+                t = torch.full((Ln,), mask, dtype=torch.int64)
+                t[0], t[-1] = bos, eos
+            tracks[name] = t.to(dev)[None]
+        coords = None if input.coordinates is None else input.coordinates.to(dev)[None]
+        u = lambda x: None if x is None else x.to(dev)[None]
+        inp = _BatchedESMProteinTensor(sequence=tracks["sequence"], structure=tracks["structure"],
+                                       secondary_structure=tracks["secondary_structure"], sasa=tracks["sasa"],
+                                       function=u(input.function), residue_annotations=u(input.residue_annotations),
+                                       coordinates=coords)
+        lo = self.logits(inp, LogitsConfig(sequence=cfg.sequence is not None, structure=cfg.structure is not None,
+                                           secondary_structure=cfg.secondary_structure is not None,
+                                           sasa=cfg.sasa is not None, return_embeddings=True))
+        out_tokens = {k: v[0].clone() for k, v in tracks.items()}
+        meta = {k: {} for k in ("entropy", "prob", "logprob", "top_prob", "topk_logprob", "topk_tokens")}
+        for name in ("sequence", "structure", "secondary_structure"):
+            tc = getattr(cfg, name)
+            if tc is None:
+                continue
+            tok = toks[name]
+            valid = sorted(set(tok.all_token_ids) - set(tok.special_token_ids) - set(tc.invalid_ids))
+            m = sample_track(getattr(lo.logits, name).contiguous(), tracks[name], tc, tok.mask_token_id, valid,
+                             generator=generator)
+            out_tokens[name] = m["sampled_tokens"][0]
+            for k in meta:
+                if m.get(k) is not None:
+                    meta[k][name] = m[k][0]
+        if cfg.sasa is not None:
+            tok = toks["sasa"]
+            valid = sorted(set(tok.all_token_ids) - set(tok.special_token_ids) - set(cfg.sasa.invalid_ids))
+            value, ent = sample_sasa_logits(lo.logits.sasa, tracks["sasa"], cfg.sasa, tok.mask_token_id, valid)
+            out_tokens["sasa"] = value[0]
+            meta["entropy"]["sasa"] = ent[0]
+        ftd = lambda dct: ForwardTrackData(**dct) if dct else None
+        pt = ESMProteinTensor(sequence=out_tokens["sequence"], structure=out_tokens["structure"],
+                              secondary_structure=out_tokens["secondary_structure"], sasa=out_tokens["sasa"],
+                              function=input.function, residue_annotations=input.residue_annotations,
+                              coordinates=input.coordinates)
+        emb = lo.embeddings
+        return ForwardAndSampleOutput(
+            protein_tensor=pt, entropy=ftd(meta["entropy"]), prob=ftd(meta["prob"]), logprob=ftd(meta["logprob"]),
+            top_prob=ftd(meta["top_prob"]), topk_logprob=ftd(meta["topk_logprob"]), topk_tokens=ftd(meta["topk_tokens"]),
+            per_residue_embedding=emb[0] if cfg.return_per_residue_embeddings else None,
+            mean_embedding=emb[0].mean(dim=0) if cfg.return_mean_embedding else None)

@@ -60,6 +60,23 @@ class GenerationConfig:
         self.schedule, self.strategy, self.temperature_annealing = "cosine", "random", True
 
 
+@dataclass
+class SamplingConfig:
+    """esm/sdk/api.py:346-365: one SamplingTrackConfig per track to sample (None = keep the input track)."""
+    sequence: SamplingTrackConfig | None = None
+    structure: SamplingTrackConfig | None = None
+    secondary_structure: SamplingTrackConfig | None = None
+    sasa: SamplingTrackConfig | None = None
+    function: SamplingTrackConfig | None = None
+    return_per_residue_embeddings: bool = False
+    return_mean_embedding: bool = False
+
+
+MAX_TOPK = 32  # esm/utils/constants/api.py:1-5
+SASA_DISCRETIZATION_BOUNDARIES = [0.8, 4.0, 9.6, 16.4, 24.5, 32.9, 42.0, 51.5, 61.2, 70.9, 81.6, 93.3, 107.2, 125.4,
+                                  151.4]  # esm/utils/constants/esm3.py:74-90
+
+
 # esm/utils/noise_schedules.py:6-35 - fraction of the track still masked at progress t (a float32 tensor, as in
 # the reference, so that the truncation in step_unmask_count sees the same rounding)
 NOISE_SCHEDULES = {
@@ -126,6 +143,29 @@ def sample_track(logits: torch.Tensor, tokens: torch.Tensor, config: SamplingTra
     if config.topk_logprobs > 0:
         out["topk_logprob"], out["topk_tokens"] = torch.topk(torch.log_softmax(logits, -1), config.topk_logprobs, dim=-1)
     return out
+
+
+def sample_sasa_logits(logits: torch.Tensor, tokens: torch.Tensor, config: SamplingTrackConfig, mask_idx: int,
+                       valid_ids: Sequence[int], mask_logits_of_invalid_ids: bool = True):
+    """SASA is decoded to a float per residue: the probability-weighted mean of the bin mid-points
+    (sampling.py:255-290; entropy: generation.py:631-639).  [B, L, 19] logits, edited in place like the reference.
+    Returns (sasa_value [B, L], entropy [B, L]).  Plain tensor ops: 19 classes, not a hot spot."""
+    if mask_logits_of_invalid_ids:
+        m = torch.ones_like(logits, dtype=torch.bool)
+        m[..., list(valid_ids)] = False
+        logits[m] = -torch.inf
+    probs = torch.softmax(logits, dim=-1)
+    max_idx = torch.argmax(probs, dim=-1)
+    bins = torch.tensor([0] + SASA_DISCRETIZATION_BOUNDARIES, dtype=torch.float)
+    bins = ((bins[:-1] + bins[1:]) / 2).to(probs.device)
+    smask = get_sampling_mask(tokens, config, mask_idx)
+    value = torch.sum(probs[..., 3:-1] * bins, dim=-1)
+    value[max_idx == 18] = float("inf")
+    value[~smask] = float("inf")
+    value[..., 0] = 0.0
+    value[..., -1] = 0.0
+    entropy = -(torch.nan_to_num(probs * logits.log_softmax(-1))).sum(-1)
+    return value, entropy
 
 
 def step_unmask_count(step: int, num_steps: int, schedule: str, total_to_sample: torch.Tensor,

@@ -259,6 +259,19 @@ def sampling_cases():
                         k + "prob": _np(meta["prob"]), k + "top_prob": _np(meta["top_prob"])})
             n_case += 1
     out["n_sample_track"] = n_case
+    # SASA decoding to floats (sampling.py:255-290) and its entropy (generation.py:631-639)
+    from esm.utils.sampling import sample_sasa_logits
+    lg = torch.randn(2, 14, 19, generator=g) * 2.0
+    lg[0, 4, 18] = 30.0  # argmax on the last class -> inf
+    tk = torch.zeros(2, 14, dtype=torch.int64)
+    tk[1, 3:6] = torch.tensor([5, 7, 9])
+    scfg = SamplingTrackConfig(only_sample_masked_tokens=True, invalid_ids=[])
+    valid = list(range(3, 19))
+    lg_in = lg.clone()
+    val = sample_sasa_logits(lg, tk, scfg, 0, valid)
+    ent = -(torch.nan_to_num(lg.softmax(-1) * lg.log_softmax(-1))).sum(-1)
+    out.update({"sasa_logits": _np(lg_in), "sasa_tokens": _np(tk), "sasa_valid": np.asarray(valid), "sasa_value": _np(val),
+                "sasa_entropy": _np(ent)})
     # step masks: which masked positions are unmasked at step t (entropy strategy is deterministic)
     toks = SimpleNamespace(sequence=EsmSequenceTokenizer(), structure=StructureTokenizer())
     n_mask = 0

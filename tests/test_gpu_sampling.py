@@ -105,3 +105,41 @@ def test_generate_sequence_with_esm3():
         m.generate_tokens(prompts, GenerationConfig(track="function"))
     with pytest.raises(ValueError):
         m.generate_tokens([ESMProteinTensor(sequence=torch.tensor([0, 5, 6, 2]))], GenerationConfig(track="sequence"))
+
+
+def test_forward_and_sample():
+    from esm_amd import synth
+    from esm_amd.api import ESMProteinTensor, LogitsConfig
+    from esm_amd.esm3 import ESM3
+    from esm_amd.sampling import SamplingConfig, SamplingTrackConfig
+    m = ESM3(128, 2, 8, 2)
+    m.load_state_dict(synth.esm3_weights(128, 2, 8, seed=51))
+    m = m.cuda()
+    seq = torch.tensor([0, 5, 6, 32, 32, 32, 7, 8, 32, 2])
+    inp = ESMProteinTensor(sequence=seq)
+    cfg = SamplingConfig(sequence=SamplingTrackConfig(temperature=0.0, topk_logprobs=3),
+                         structure=SamplingTrackConfig(temperature=0.0),
+                         sasa=SamplingTrackConfig(), return_per_residue_embeddings=True, return_mean_embedding=True)
+    out = m.forward_and_sample(inp, cfg)
+    pt = out.protein_tensor
+    s = pt.sequence.cpu()
+    keep = seq != 32
+    assert torch.equal(s[keep], seq[keep]) and not (s == 32).any()
+    # argmax over the valid vocabulary of the logits the model returns for the same input
+    full = ESMProteinTensor(sequence=seq.cuda(), structure=torch.tensor([4098] + [4096] * 8 + [4097]).cuda(),
+                            secondary_structure=torch.zeros(10, dtype=torch.long).cuda(), sasa=torch.zeros(10, dtype=torch.long).cuda())
+    lg = m.logits(full, LogitsConfig(sequence=True, structure=True)).logits
+    valid = torch.zeros(64, dtype=torch.bool)
+    valid[4:31] = True
+    want = lg.sequence[0].cpu().masked_fill(~valid, -float("inf")).argmax(-1)
+    assert torch.equal(s[~keep], want[~keep])
+    st = pt.structure.cpu()
+    assert st[0] == 4098 and st[-1] == 4097 and torch.equal(st[1:-1], lg.structure[0, 1:-1, :4096].cpu().argmax(-1))
+    assert out.entropy.sequence.shape == (10,) and out.topk_tokens.sequence.shape == (10, 3)
+    assert out.logprob.sequence[keep.cuda()].abs().max() == 0 and (out.prob.sequence <= 1.0 + 1e-6).all()
+    assert pt.sasa.shape == (10,) and pt.sasa[0] == 0 and pt.sasa[-1] == 0 and out.entropy.sasa.shape == (10,)
+    assert out.per_residue_embedding.shape == (10, 128)
+    torch.testing.assert_close(out.mean_embedding, out.per_residue_embedding.mean(0))
+    assert pt.secondary_structure.shape == (10,) and out.entropy.secondary_structure is None
+    with pytest.raises(NotImplementedError):
+        m.forward_and_sample(inp, SamplingConfig(function=SamplingTrackConfig()))

@@ -70,3 +70,14 @@ def test_generation_config_validation():
     c = GenerationConfig(track="sequence")
     c.use_entropy_based_unmasking_strategy()
     assert (c.schedule, c.strategy, c.temperature_annealing) == ("cosine", "entropy", False)
+
+
+def test_sasa_decoding_matches_reference():
+    from esm_amd.sampling import sample_sasa_logits
+    lg = torch.from_numpy(G["sasa_logits"]).clone()
+    val, ent = sample_sasa_logits(lg, torch.from_numpy(G["sasa_tokens"]), SamplingTrackConfig(), 0, G["sasa_valid"].tolist())
+    want = torch.from_numpy(G["sasa_value"])
+    assert torch.equal(torch.isinf(val), torch.isinf(want))
+    fin = torch.isfinite(want)
+    torch.testing.assert_close(val[fin], want[fin], rtol=1e-6, atol=1e-6)
+    torch.testing.assert_close(ent, torch.from_numpy(G["sasa_entropy"]), rtol=1e-6, atol=1e-6)
