@@ -311,6 +311,9 @@ def main():
         return text_cases()
     if "--sampling-only" in sys.argv:
         return sampling_cases()
+    if "--600m-only" in sys.argv:
+        return esmc_case("esmc_600m_2x128", 1152, 18, 36, [128, 77], wseed=32, tseed=310, store_hidden=(0, 17, 35),
+                         token_stride=2)
     if "--vqdec-only" in sys.argv:
         return stack_case("stack_d1280_vqdec", 1280, 20, 30, 64, wseed=61, scale_residue=False)
     text_cases()
@@ -345,6 +348,8 @@ def main():
     # (iii) full-depth ESMC-300M-shaped (C1 geometry), 2 x 128
     esmc_case("esmc_300m_2x128", 960, 15, 30, [128, 101], wseed=31, tseed=300, store_hidden=(0, 14, 29),
               token_stride=2)
+    # the headline model shape at full depth (C2 geometry: d1152, 18 heads, 36 layers), 2 x 128
+    esmc_case("esmc_600m_2x128", 1152, 18, 36, [128, 77], wseed=32, tseed=310, store_hidden=(0, 17, 35), token_stride=2)
     # (iv) geometric attention variants
     for v in ("plain", "nostruct", "multichain", "binpacked", "onerow_frameless"):
         geom_case(f"geom_{v}", 128, 8, 2, 48, wseed=41, variant=v)

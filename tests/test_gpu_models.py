@@ -25,7 +25,7 @@ def emb_ok(got, ref, cos_min=COS_MIN):
     assert rel <= 0.03, rel
 
 
-@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128"])
+@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128", "esmc_600m_2x128"])
 def test_esmc_vs_golden(name):
     from esm_amd.esmc import ESMC
     fx = G.load(name)

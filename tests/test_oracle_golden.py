@@ -15,7 +15,7 @@ def _close(a, b, tol=TOL):
     assert err <= tol * scale, (err, scale)
 
 
-@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128"])
+@pytest.mark.parametrize("name", ["esmc_tiny_bool", "esmc_tiny_binpacked", "esmc_300m_2x128", "esmc_600m_2x128"])
 def test_esmc(name):
     fx = G.load(name)
     w = G.weights_for(fx)
