@@ -49,6 +49,17 @@ def esmc_case(name, d, H, NL, lengths, wseed, tseed, sequence_id=None, pad_to=No
     )
     if sequence_id is not None:
         arrays["sequence_id"] = _np(sequence_id)
+    if NL >= 30:  # calibration: the reference's OWN bf16 path against its fp32 path on these inputs
+        mb = m.to(torch.bfloat16)
+        with torch.no_grad():
+            ob = mb(tok, sequence_id=sequence_id)
+        valid = tok != 1
+        cos = torch.nn.functional.cosine_similarity(ob.embeddings.float()[valid], out.embeddings[valid], dim=-1)
+        arrays["ref_bf16_cos_min"] = float(cos.min())
+        arrays["ref_bf16_logit_maxdiff"] = float((ob.sequence_logits.float()[valid] - out.sequence_logits[valid]).abs().max())
+        arrays["ref_logit_absmax"] = float(out.sequence_logits[valid].abs().max())
+        print(name, "reference bf16 vs fp32: cos_min", arrays["ref_bf16_cos_min"], "logit maxdiff", arrays["ref_bf16_logit_maxdiff"],
+              "of", arrays["ref_logit_absmax"])
     save(name, **arrays)
 
 
@@ -312,6 +323,7 @@ def main():
     if "--sampling-only" in sys.argv:
         return sampling_cases()
     if "--600m-only" in sys.argv:
+        esmc_case("esmc_300m_2x128", 960, 15, 30, [128, 101], wseed=31, tseed=300, store_hidden=(0, 14, 29), token_stride=2)
         return esmc_case("esmc_600m_2x128", 1152, 18, 36, [128, 77], wseed=32, tseed=310, store_hidden=(0, 17, 35),
                          token_stride=2)
     if "--vqdec-only" in sys.argv:
