@@ -93,3 +93,25 @@ def embed_fasta(model, path, token_budget: int = 32768, pooling: str = "mean", g
     """-> (headers, embeddings) for every record of a FASTA file (reference reader: esm/utils/parsing.py:40-58)."""
     entries = list(read_sequences(path))
     return [e.header for e in entries], embed_sequences(model, [e.sequence for e in entries], token_budget, pooling, group)
+
+
+def save_embeddings(path, headers: Sequence[str], embeddings: torch.Tensor, dtype=torch.float32) -> None:
+    """Wire/storage format of a pooled result: one safetensors file holding `embeddings`
+    [n, d] plus the FASTA headers (JSON list) in the file metadata - memory-mappable, no pickle."""
+    import json
+    from safetensors.torch import save_file
+    if embeddings.ndim != 2 or embeddings.shape[0] != len(headers):
+        raise ValueError("embeddings must be [n_sequences, d] with one header per row")
+    save_file({"embeddings": embeddings.detach().to("cpu", dtype).contiguous()}, str(path),
+              metadata={"headers": json.dumps(list(headers)), "format": "esm_amd.pooled_embeddings.v1"})
+
+
+def load_embeddings(path):
+    """-> (headers, embeddings) written by save_embeddings."""
+    import json
+    from safetensors import safe_open
+    with safe_open(str(path), framework="pt") as f:
+        meta = f.metadata() or {}
+        if meta.get("format") != "esm_amd.pooled_embeddings.v1":
+            raise ValueError("not an esm_amd pooled-embeddings file")
+        return json.loads(meta["headers"]), f.get_tensor("embeddings")

@@ -85,3 +85,15 @@ def test_tokenize_packs_covers_every_sequence_once():
         n = gather_pack(tokens, offsets, p, buf)
         assert n == sum(lengths[i] for i in p) <= 1024
         assert buf[:n].tolist() == sum((tokenize_sequence(seqs[i], tok).tolist() for i in p), [])
+
+
+def test_save_load_embeddings(tmp_path):
+    from esm_amd.pipeline import load_embeddings, save_embeddings
+    emb = torch.randn(3, 16)
+    save_embeddings(tmp_path / "e.safetensors", ["a b", "c", "d|e"], emb)
+    h, e = load_embeddings(tmp_path / "e.safetensors")
+    assert h == ["a b", "c", "d|e"] and torch.equal(e, emb)
+    save_embeddings(tmp_path / "h.safetensors", ["x"], emb[:1], dtype=torch.bfloat16)
+    assert load_embeddings(tmp_path / "h.safetensors")[1].dtype == torch.bfloat16
+    with pytest.raises(ValueError):
+        save_embeddings(tmp_path / "bad.safetensors", ["only one"], emb)
