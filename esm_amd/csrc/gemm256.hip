@@ -117,22 +117,24 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
                 for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     bf16x8 af[4][2], bfr[2][2][2];  // A sub-tile of the current qm; B sub-tiles of BOTH qn
 
-    auto issue_unit = [&](int u, int kt) {
-        if (dbg & 1) return;
-        char* dst = smem + (kt & 1) * KBUF + u * UNIT + dma_dst;
-        const char* base = ((u == 0 || u == 3) ? wbase : abase) + (size_t)kt * (BK * 2);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + soff[u][0]), LDS_PTR(dst), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + soff[u][1]), LDS_PTR(dst + 1024), 16, 0, 0);
-    };
+    // buffer form of the LDS-DMA (buffer_load_dwordx4 ... offen lds): tile base in a scalar descriptor, per-lane
+    // 32-bit offset, K offset in an SGPR - no per-piece 64-bit vector address arithmetic in the loop (2-3 % faster
+    // than global_load_lds with a per-lane 64-bit address, measured on the 288-tile kernel)
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
     auto issue_piece = [&](int u, int i, int kt) {
         if (dbg & 1) return;
         char* dst = smem + (kt & 1) * KBUF + u * UNIT + dma_dst + i * 1024;
 #ifdef ESMK_SAMEDMA  /* timing experiment only: every tile streams the same 64 KiB */
-        const char* base = ((u == 0 || u == 3) ? (const char*)W : (const char*)A);
+        const int koff = 0;
 #else
-        const char* base = ((u == 0 || u == 3) ? wbase : abase) + (size_t)kt * (BK * 2);
+        const int koff = kt * (BK * 2);
 #endif
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + soff[u][i]), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds((u == 0 || u == 3) ? rW : rA, LDS_PTR(dst), 16, (int)soff[u][i], koff, 0, 0);
+    };
+    auto issue_unit = [&](int u, int kt) {
+        issue_piece(u, 0, kt);
+        issue_piece(u, 1, kt);
     };
     auto read_a_kk = [&](const char* unit, int kk) {
         if (dbg & 2) return;

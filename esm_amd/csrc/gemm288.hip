@@ -76,14 +76,17 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
         const int ur = (p - (qm - 1) * 12) * 8 + (lane >> 3);
         soffQ[j] = a_row_off(ur, qm) + (((lane & 7) ^ ((ur >> 1) & 7)) << 4);
     }
+    // buffer form of the LDS-DMA: tile base in a scalar descriptor, per-lane 32-bit offset, K offset in an SGPR -
+    // no per-piece 64-bit vector address arithmetic in the loop
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)wbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)abase, 0, 0x7fffffff, 0x00020000);
     auto issue_P = [&](int j, int kt) {  // j compile-time after unrolling
         char* dst = smem + (kt & 1) * KBUF + (wave + 8 * j) * 1024;
-        const char* base = (j < 4 ? abase : wbase) + (size_t)kt * (BK * 2);
-        __builtin_amdgcn_global_load_lds(GLB_PTR(base + soffP[j]), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(j < 4 ? rA : rW, LDS_PTR(dst), 16, (int)soffP[j], kt * (BK * 2), 0, 0);
     };
     auto issue_Q = [&](int j, int kt) {
         char* dst = smem + (kt & 1) * KBUF + OFF_UA1 + (wave + 8 * j) * 1024;
-        __builtin_amdgcn_global_load_lds(GLB_PTR(wbase + (size_t)kt * (BK * 2) + soffQ[j]), LDS_PTR(dst), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, LDS_PTR(dst), 16, (int)soffQ[j], kt * (BK * 2), 0, 0);
     };
     auto issue_tile = [&](int kt) {
 #pragma unroll
