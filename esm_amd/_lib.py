@@ -70,6 +70,9 @@ SIGNATURES = {
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "esmk_sample_track": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "esmk_dim6_frames": (C.c_int, [vp, C.c_int, C.c_float, vp, vp, C.c_int, vp]),
+    "esmk_categorical_mean": (C.c_int, [vp, C.c_int, C.c_int, C.c_float, C.c_float, vp, vp]),
+    "esmk_pairwise_pae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "esmk_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_head_forward": (C.c_int, [C.POINTER(EsmkHead), vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "esmk_event_create": (C.c_int, [C.POINTER(vp)]),

@@ -193,14 +193,17 @@ def segment_mean(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
 class HeadEngine:
     """RegressionHead (reference esm/layers/regression_head.py:17-22) on esmk_head_forward."""
 
-    def __init__(self, weights: dict, prefix: str, d_model: int, out_dim: int, device):
+    def __init__(self, weights: dict, prefix: str, d_model: int, out_dim: int, device, names=("0", "2", "3")):
+        """names: sub-module names of (first Linear, LayerNorm, output Linear): ("0", "2", "3") in the reference's
+        nn.Sequential heads, ("dense", "norm", "output") / ("ffn1", "norm", "proj") in the VQ-VAE decoder's."""
         self.lib = L.lib()
         self.device = torch.device(device)
         self.d, self.out_dim = d_model, out_dim
+        lin0, norm, lin1 = (prefix + n for n in names)
         self._keep = [
-            pack_weight(weights[prefix + "0.weight"], device), _f32(weights[prefix + "0.bias"], device),
-            _f32(weights[prefix + "2.weight"], device), _f32(weights[prefix + "2.bias"], device),
-            pack_weight(weights[prefix + "3.weight"], device), _f32(weights[prefix + "3.bias"], device),
+            pack_weight(weights[lin0 + ".weight"], device), _f32(weights[lin0 + ".bias"], device),
+            _f32(weights[norm + ".weight"], device), _f32(weights[norm + ".bias"], device),
+            pack_weight(weights[lin1 + ".weight"], device), _f32(weights[lin1 + ".bias"], device),
         ]
         h = L.EsmkHead()
         h.w0, h.b0, h.ln_g, h.ln_b, h.w3, h.b3 = [L.ptr(t) for t in self._keep]

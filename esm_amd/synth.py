@@ -32,7 +32,9 @@ def _kind(name: str):
     if name.endswith("_scale_per_head"):
         return 0.0, 0.5
     is_ln = any(s in name for s in ("layernorm_qkv.0.", "q_ln.", "k_ln.", "ffn.0.", "s_norm.", "transformer.norm.")) \
-        or (("_head.2." in name) or ("sequence_head.2." in name))
+        or (("_head.2." in name) or ("sequence_head.2." in name)) \
+        or any(s in name for s in ("affine_output_projection.norm.", "pairwise_classification_head.norm.", "plddt_head.norm.",
+                                   "decoder_stack.norm."))
     if is_ln and leaf == "weight":
         return 1.0, 0.1
     if leaf == "bias":
@@ -100,6 +102,20 @@ def esm3_shapes(d: int, n_layers: int, v_heads: int):
     s.update(trunk_shapes("transformer.", d, n_layers, v_heads=v_heads, n_layers_geom=1))
     for name, out in ESM3_HEAD_DIMS.items():
         s.update(head_shapes(f"output_heads.{name}_head.", d, out))
+    return s
+
+
+def vqdec_shapes(d: int, n_layers: int):
+    """StructureTokenDecoder state_dict (esm/models/vqvae.py:325-363)."""
+    s = {"embed.weight": (4101, d)}
+    s.update(trunk_shapes("decoder_stack.", d, n_layers))
+    a, p, q = "affine_output_projection.", "pairwise_classification_head.", "plddt_head."
+    s.update({a + "ffn1.weight": (d, d), a + "ffn1.bias": (d,), a + "norm.weight": (d,), a + "norm.bias": (d,),
+              a + "proj.weight": (23, d), a + "proj.bias": (23,),
+              p + "downproject.weight": (128, d), p + "linear1.weight": (128, 128), p + "norm.weight": (128,),
+              p + "norm.bias": (128,), p + "linear2.weight": (224, 128),
+              q + "dense.weight": (d, d), q + "dense.bias": (d,), q + "norm.weight": (d,), q + "norm.bias": (d,),
+              q + "output.weight": (50, d), q + "output.bias": (50,)})
     return s
 
 

@@ -279,6 +279,35 @@ int esmk_sample_track(float* logits, int R, int V, const uint8_t* valid, float t
                       float* entropy, float* logprob, float* top_prob, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Output side of the VQ-VAE structure decoder (StructureTokenDecoder.decode, reference
+ * esm/models/vqvae.py:365-437).  The decoder stack itself is esmk_trunk_forward (residual_scale = 1,
+ * vqvae.py:337-339) and the two RegressionHead-shaped MLPs are esmk_head_forward; these three follow them.
+ *
+ * esmk_dim6_frames: Dim6RotStructureHead.forward after `self.proj` (esm/layers/structure_proj.py:46-63, with
+ *   affine=None and an all-False affine_mask as decode() passes).  proj f32 [M, ldp]: columns 0-2 translation,
+ *   3-5 / 6-8 the two direction vectors (the 14 torsion columns are unused).  affine f32 [M, 12] =
+ *   [rotation row-major 9 | translation 3] ("tensor7_affine"), bb f32 [M, 3, 3] = N, CA, C ("bb_pred").
+ * esmk_categorical_mean: CategoricalMixture(logits, bins=V, start=lo, end=hi).mean() (vqvae.py:114-136):
+ *   out[r] = sum_v softmax(logits[r])[v] * (lo + (v + 0.5) (hi - lo) / V).  pLDDT: V = 50, lo = 0, hi = 1.
+ * esmk_pairwise_pae: PairwisePredictionHead.forward on the down-projected features (vqvae.py:83-95) restricted to
+ *   the 64 predicted-aligned-error bins, fused with compute_predicted_aligned_error and compute_tm
+ *   (esm/utils/structure/predicted_aligned_error.py:37-66); no [B, L, L, *] intermediate is written.
+ *     qk      f32 [B*L, 128]  = downproject(x): columns 0-63 "q", 64-127 "k" (vqvae.py:79,83)
+ *     w1      bf16 [128, 128] = linear1.weight (row-major, 16-byte aligned)
+ *     w2      bf16 [64, 128]  = linear2.weight[pae rows] * norm.weight (LayerNorm scale folded in)
+ *     b2      f32 [64]        = linear2.weight[pae rows] . norm.bias   (LayerNorm shift folded in)
+ *     aa_mask u8 [B, L]       = 1 where the token is a structure code (not a special token, vqvae.py:412)
+ *     pae     f32 [B, L, L]   pae[b, a, c] pairs (k_a, q_c) as in the reference's [B, L, L] output
+ *     ptm     f32 [B]
+ * ------------------------------------------------------------------------------------------ */
+int esmk_dim6_frames(const float* proj, int ldp, float trans_scale, float* affine, float* bb, int M,
+                     esmk_stream_t stream);
+int esmk_categorical_mean(const float* logits, int R, int V, float lo, float hi, float* out, esmk_stream_t stream);
+int esmk_pairwise_pae(const float* qk, const void* w1_bf16, const void* w2_bf16, const float* b2,
+                      const uint8_t* aa_mask, int B, int L, float max_bin, float* pae, float* ptm,
+                      esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Timing helpers (thin wrappers over hipEvent*, so that a harness without HIP headers can time kernels on
  * the stream they are launched on).  No counterpart in the reference.
  * ------------------------------------------------------------------------------------------ */

@@ -90,6 +90,40 @@ def stack_case(name, d, H, NL, L, wseed, scale_residue=True):
          post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4, scale_residue=int(scale_residue))
 
 
+def vqdec_tokens(lengths, L, seed):
+    """Structure tokens [B, L]: BOS, codes (with one MASK and one CHAINBREAK inside row 0), EOS, PAD after."""
+    g = torch.Generator().manual_seed(seed)
+    tok = torch.full((len(lengths), L), 4099, dtype=torch.int64)
+    for b, n in enumerate(lengths):
+        tok[b, :n] = torch.randint(0, 4096, (n,), generator=g)
+        tok[b, 0], tok[b, n - 1] = 4098, 4097
+    tok[0, 5], tok[0, 9] = 4096, 4100
+    return tok, tok != 4099
+
+
+def vqdec_case(name, d, H, NL, L, lengths, wseed, tseed, sequence_id=None):
+    """StructureTokenDecoder.decode end to end (vqvae.py:365-437), plus the reference's own bf16 drift."""
+    w = synth.make_weights(synth.vqdec_shapes(d, NL), seed=wseed)
+    m = ref_import.build_vqdec(d, H, NL, w)
+    tok, mask = vqdec_tokens(lengths, L, tseed)
+    with torch.no_grad():
+        out = m.decode(tok, attention_mask=mask, sequence_id=sequence_id)
+    arrays = dict(kind="vqdec", d=d, H=H, NL=NL, wseed=wseed, tokens=_np(tok), attention_mask=_np(mask))
+    if sequence_id is not None:
+        arrays["sequence_id"] = _np(sequence_id)
+    for k, v in out.items():
+        arrays[k] = _np(v)
+    mb = m.to(torch.bfloat16)
+    with torch.no_grad():
+        ob = mb.decode(tok, attention_mask=mask, sequence_id=sequence_id)
+    for k, v in out.items():
+        arrays["ref_bf16_maxdiff_" + k] = float((ob[k].float() - v).abs().max())
+        arrays["ref_bf16_meandiff_" + k] = float((ob[k].float() - v).abs().mean())
+        print(name, k, "absmax", float(v.abs().max()), "reference bf16 drift max", arrays["ref_bf16_maxdiff_" + k],
+              "mean", arrays["ref_bf16_meandiff_" + k])
+    save(name, **arrays)
+
+
 def esm3_inputs(B, L, lengths, seed, with_tracks=True):
     g = torch.Generator().manual_seed(seed)
     seq = synth.synth_tokens(lengths, pad_to=L, seed=seed)
@@ -315,6 +349,15 @@ def sampling_cases():
     save("sampling", **out)
 
 
+def vqdec_cases():
+    # tiny (2 blocks, d 128) incl. a bin-packed sequence_id, and the released geometry (30 blocks, d 1280, 20 heads)
+    vqdec_case("vqdec_tiny", 128, 2, 2, 40, [40, 27], wseed=71, tseed=700)
+    sid = torch.zeros(2, 40, dtype=torch.int64)
+    sid[1, 27:] = 1
+    vqdec_case("vqdec_tiny_seqid", 128, 2, 2, 40, [40, 27], wseed=71, tseed=701, sequence_id=sid)
+    vqdec_case("vqdec_d1280_30l", 1280, 20, 30, 48, [48, 31], wseed=72, tseed=702)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -328,6 +371,8 @@ def main():
                          token_stride=2)
     if "--vqdec-only" in sys.argv:
         return stack_case("stack_d1280_vqdec", 1280, 20, 30, 64, wseed=61, scale_residue=False)
+    if "--vqdec-model-only" in sys.argv:
+        return vqdec_cases()
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -379,6 +424,8 @@ def main():
               extra=dict(chain_id=chain, sequence_id=sid))
     esm3_case("esm3_d1536_2layer", 1536, 24, 256, 2, 1, 64, [64], wseed=53, iseed=503, with_tracks=False,
               big_stride=8)
+    # (vii) VQ-VAE structure decoder, tokens -> coordinates / pLDDT / pTM / pae
+    vqdec_cases()
 
 
 if __name__ == "__main__":

@@ -97,6 +97,15 @@ def build_stack(d_model, n_heads, n_layers, weights: dict, v_heads=None, n_layer
     return m
 
 
+def build_vqdec(d_model, n_heads, n_layers, weights: dict):
+    install()
+    from esm.models.vqvae import StructureTokenDecoder
+
+    m = StructureTokenDecoder(d_model=d_model, n_heads=n_heads, n_layers=n_layers).eval()
+    m.load_state_dict(weights, strict=True)
+    return m
+
+
 def build_frames(coords):
     install()
     from esm.utils.structure.affine3d import build_affine3d_from_coordinates

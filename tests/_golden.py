@@ -35,6 +35,8 @@ def weights_for(fx):
         shapes = {k: v for k, v in synth.trunk_shapes("", d, 1, v_heads=int(fx["VH"]), n_layers_geom=1).items()
                   if "geom_attn" in k}
         return synth.make_weights(shapes, seed=ws)
+    if kind == "vqdec":
+        return synth.make_weights(synth.vqdec_shapes(d, int(fx["NL"])), seed=ws)
     raise ValueError(kind)
 
 

@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from oracle import trunk_ref
+from oracle import trunk_ref, vqvae_ref
 from tests import _golden as G
 
 TOL = 2e-5  # fp32 vs fp32, different op order
@@ -77,3 +77,16 @@ def test_esm3(name):
         _close(out[k], G.t(fx[k]))
     for k in ("structure_logits", "function_logits", "residue_logits"):
         _close(out[k][:, ::bs], G.t(fx[k]))
+
+
+VQDEC_KEYS = ("tensor7_affine", "bb_pred", "plddt", "ptm", "predicted_aligned_error")
+
+
+@pytest.mark.parametrize("name", ["vqdec_tiny", "vqdec_tiny_seqid", "vqdec_d1280_30l"])
+def test_vqvae_structure_decoder(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
+    out = vqvae_ref.decode(G.t(fx["tokens"]), w, int(fx["H"]), int(fx["NL"]), sequence_id=sid)
+    for k in VQDEC_KEYS:
+        _close(out[k], G.t(fx[k]), 1e-4 if name == "vqdec_d1280_30l" else TOL)
