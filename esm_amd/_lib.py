@@ -66,6 +66,9 @@ SIGNATURES = {
     "esmk_frames": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
     "esmk_geom_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_geom_attn": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
+    "esmk_geom_attn_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp]),
+    "esmk_knn_neighbourhoods": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "esmk_vq_quantize": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esmk_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(EsmkTrunk), C.c_int]),
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),

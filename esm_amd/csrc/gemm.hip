@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(const __bf16
         } else if constexpr (EPI == ESMK_EPI_SWIGLU) {
 #pragma unroll
             for (int i = 0; i < 4; i += 2)
-                epi_swiglu4(acc[i][j], acc[i + 1][j], t, ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4, N >> 1, out);
+                epi_swiglu4(acc[i][j], acc[i + 1][j], t, ((c0 + wr * 64) >> 1) + (i >> 1) * 16 + q4, N >> 1, out, bias);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) epi_store4<EPI>(acc[i][j], t, c0 + wr * 64 + i * 16 + q4, N, bias, alpha, out);
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
             g += *(const f32x4*)(p + s * sstride);
             u += *(const f32x4*)(p + s * sstride + 16);
         }
-        epi_swiglu4(g, u, t, c, N >> 1, out);
+        epi_swiglu4(g, u, t, c, N >> 1, out, bias);
     } else {
         const float* p = part + (size_t)t * ldp + c;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -329,14 +329,17 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         const int ov = gemm_tile_override();
         // measured crossover (tools/gemm_bench.py, M = 512 ... 32768): the 256-tile kernel wins once there are
         // about half as many 256x256 tiles as CUs; below that the 128-tile kernel fills the chip better.
-        const bool big = (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
+        // a bias with the bf16 / SwiGLU epilogues (bias=True block variants: VQ-VAE structure encoder) is applied by
+        // the 128-tile kernel and the split-K reduce only; those stacks are small
+        const bool bias128 = bias && (epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU);
+        const bool big = !bias128 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
         // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
         static int use288 = -1;
         if (use288 < 0) { const char* e5 = getenv("ESMK_GEMM_288"); use288 = e5 ? atoi(e5) : 1; }
-        if (use288 && ov == 0 && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
+        if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
             (long long)((M + 255) / 256) * (N / 288) >= 128)
             return esmk_gemm288(A, lda, W, M, N, K, alpha, out, s);
-        if (ov == 256 || (ov == 0 && big)) {
+        if ((ov == 256 && !bias128) || (ov == 0 && big)) {
             // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
             // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call
             // so that tests can exercise both.

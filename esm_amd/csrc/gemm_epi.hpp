@@ -9,8 +9,14 @@ __device__ __forceinline__ float silu(float x) {
 }
 
 // SwiGLU: g/u = gate/up accumulators of the same 4 channels; c = OUTPUT channel, hw = output width.
-__device__ __forceinline__ void epi_swiglu4(const f32x4 g, const f32x4 u, int t, int c, int hw, void* out) {
+// bias (optional) is ffn.1.bias in the reference's row order: gate rows [0, hw), up rows [hw, 2 hw).
+__device__ __forceinline__ void epi_swiglu4(f32x4 g, f32x4 u, int t, int c, int hw, void* out,
+                                            const float* __restrict__ bias = nullptr) {
     if (c >= hw) return;
+    if (bias) {
+        g += *(const f32x4*)(bias + c);  // hw % 16 == 0 (SwiGLU packing) and c % 4 == 0
+        u += *(const f32x4*)(bias + hw + c);
+    }
     u32x2 v;
     v.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
     v.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
@@ -25,6 +31,7 @@ __device__ __forceinline__ void epi_store4(f32x4 v, int t, int c, int N, const f
     if constexpr (EPI == ESMK_EPI_RESIDUAL) {
         float* o = (float*)out + (size_t)t * N + c;
         f32x4 x = *(f32x4*)o;
+        if (bias) v += *(const f32x4*)(bias + c);  // N % 4 == 0 for this epilogue
         x += v * alpha;
         *(f32x4*)o = x;
     } else if constexpr (EPI == ESMK_EPI_BF16 || EPI == ESMK_EPI_BIAS_GELU) {
@@ -33,6 +40,10 @@ __device__ __forceinline__ void epi_store4(f32x4 v, int t, int c, int N, const f
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r] + (c + r < N ? bias[c + r] : 0.f));
         } else {
+            if (bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] += (c + r < N ? bias[c + r] : 0.f);
+            }
             v *= alpha;
         }
         if (full) {

@@ -154,6 +154,10 @@ __global__ __launch_bounds__(256) void geom_prep_kernel(const float* __restrict_
 constexpr int GQ = 128;  // queries per block (one per thread)
 constexpr int GK = 128;  // keys per LDS tile
 
+// ZF = mask_and_zero_frameless (geom_attention.py:145-146): true -> rows without a frame give zeros (ESM3);
+// false (VQ-VAE structure encoder) -> they attend like any other query, and a query whose keys are ALL masked gets
+// the reference's uniform softmax over every key of its row (all scores collapse to finfo.min).
+template <bool ZF>
 __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__ qrec, const float* __restrict__ krec,
                                                        const float* __restrict__ affine,
                                                        const uint8_t* __restrict__ amask,
@@ -175,6 +179,7 @@ __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__
     const bool framed = amask[qt] != 0;
 
     float m = -FLT_MAX, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f;
+    float ux = 0.f, uy = 0.f, uz = 0.f;  // !ZF: plain sum of v over the row (uniform fallback)
     for (int k0 = r0; k0 < r1; k0 += GK) {
         const int nk = min(GK, r1 - k0);
         __syncthreads();
@@ -191,6 +196,7 @@ __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__
             const float dx = qa[3] - ka[3], dy = qb[0] - kb[0], dz = qb[1] - kb[1];
             float s = qa[0] * ka[0] + qa[1] * ka[1] + qa[2] * ka[2] - sqrtf(dx * dx + dy * dy + dz * dz);
             s += (__float_as_int(kc[2]) == my_seq) ? LOG2E : 0.f;
+            if constexpr (!ZF) { ux += kb[2]; uy += kb[3]; uz += kc[0]; }
             if (ok) {
                 if (s > m) {
                     const float a = __builtin_amdgcn_exp2f(m - s);
@@ -207,13 +213,75 @@ __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__
     }
     if (!active) return;
     __bf16* o = out + (size_t)qi * ld_out + h * 3;
-    if (!framed || l == 0.f) {  // mask_and_zero_frameless (geom_attention.py:145-146)
-        o[0] = (__bf16)0.f; o[1] = (__bf16)0.f; o[2] = (__bf16)0.f;
-        return;
+    if constexpr (ZF) {
+        if (!framed || l == 0.f) {  // mask_and_zero_frameless (geom_attention.py:145-146)
+            o[0] = (__bf16)0.f; o[1] = (__bf16)0.f; o[2] = (__bf16)0.f;
+            return;
+        }
+    } else if (l == 0.f) {
+        l = (float)(r1 - r0); ox = ux; oy = uy; oz = uz;
     }
     const float inv = 1.0f / l;
     ox *= inv; oy *= inv; oz *= inv;
     const float* R = affine + (size_t)qi * 12;  // inverse rotation = R^T . o
+    o[0] = (__bf16)(R[0] * ox + R[3] * oy + R[6] * oz);
+    o[1] = (__bf16)(R[1] * ox + R[4] * oy + R[7] * oz);
+    o[2] = (__bf16)(R[2] * ox + R[5] * oy + R[8] * oz);
+}
+
+// Rows of at most 16 tokens (the structure encoder's kNN neighbourhoods, vqvae.py:193-263): 16 rows per 256-thread
+// block, one thread per (row, slot); the <= 16 keys of a row are read straight from the K records (the 16 threads
+// of a row read the same addresses - one broadcast load each).
+template <bool ZF>
+__global__ __launch_bounds__(256) void geom_attn_small_kernel(const float* __restrict__ qrec, const float* __restrict__ krec,
+                                                              const float* __restrict__ affine,
+                                                              const uint8_t* __restrict__ amask,
+                                                              const int* __restrict__ seq_id,
+                                                              const int* __restrict__ chain_id,
+                                                              const int* __restrict__ row_cu, int n_rows,
+                                                              __bf16* __restrict__ out, int ld_out, int M, int H) {
+    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), h = blockIdx.y;
+    if (row >= n_rows) return;
+    const int r0 = row_cu[row], r1 = row_cu[row + 1];
+    const int qi = r0 + (threadIdx.x & 15);
+    if (qi >= r1) return;
+    const float* q = qrec + ((size_t)h * M + qi) * 8;
+    const f32x4 qa = *(const f32x4*)q, qb = *(const f32x4*)(q + 4);
+    const int my_seq = seq_id[qi], my_chain = chain_id[qi];
+    float m = -FLT_MAX, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
+    for (int k = r0; k < r1; ++k) {
+        const float* kp = krec + ((size_t)h * M + k) * 12;
+        const f32x4 ka = *(const f32x4*)kp, kb = *(const f32x4*)(kp + 4), kc = *(const f32x4*)(kp + 8);
+        const bool ok = (kc[1] != 0.f) && (__float_as_int(kc[3]) == my_chain);
+        const float dx = qa[3] - ka[3], dy = qb[0] - kb[0], dz = qb[1] - kb[1];
+        float s = qa[0] * ka[0] + qa[1] * ka[1] + qa[2] * ka[2] - sqrtf(dx * dx + dy * dy + dz * dz);
+        s += (__float_as_int(kc[2]) == my_seq) ? LOG2E : 0.f;
+        if constexpr (!ZF) { ux += kb[2]; uy += kb[3]; uz += kc[0]; }
+        if (ok) {
+            if (s > m) {
+                const float a = __builtin_amdgcn_exp2f(m - s);
+                l *= a; ox *= a; oy *= a; oz *= a;
+                m = s;
+            }
+            const float p = __builtin_amdgcn_exp2f(s - m);
+            l += p;
+            ox += p * kb[2];
+            oy += p * kb[3];
+            oz += p * kc[0];
+        }
+    }
+    __bf16* o = out + (size_t)qi * ld_out + h * 3;
+    if constexpr (ZF) {
+        if (amask[qi] == 0 || l == 0.f) {
+            o[0] = (__bf16)0.f; o[1] = (__bf16)0.f; o[2] = (__bf16)0.f;
+            return;
+        }
+    } else if (l == 0.f) {
+        l = (float)(r1 - r0); ox = ux; oy = uy; oz = uz;
+    }
+    const float inv = 1.0f / l;
+    ox *= inv; oy *= inv; oz *= inv;
+    const float* R = affine + (size_t)qi * 12;
     o[0] = (__bf16)(R[0] * ox + R[3] * oy + R[6] * oz);
     o[1] = (__bf16)(R[1] * ox + R[4] * oy + R[7] * oz);
     o[2] = (__bf16)(R[2] * ox + R[5] * oy + R[8] * oz);
@@ -240,11 +308,20 @@ extern "C" int esmk_geom_attn(const float* proj, const float* affine, const uint
                               const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
                               const float* dist_scale, const float* rot_scale, void* out, int ld_out, void* scratch,
                               int M, int H, esmk_stream_t stream) {
+    return esmk_geom_attn_ex(proj, affine, affine_mask, seq_id, chain_id, row_cu, n_rows, max_row_len, dist_scale,
+                             rot_scale, out, ld_out, scratch, M, H, 1, stream);
+}
+
+extern "C" int esmk_geom_attn_ex(const float* proj, const float* affine, const uint8_t* affine_mask,
+                                 const int32_t* seq_id, const int32_t* chain_id, const int32_t* row_cu, int n_rows,
+                                 int max_row_len, const float* dist_scale, const float* rot_scale, void* out, int ld_out,
+                                 void* scratch, int M, int H, int mask_and_zero_frameless, esmk_stream_t stream) {
     if (M == 0 || n_rows == 0 || max_row_len == 0) return ESMK_OK;
     if (!proj || !affine || !affine_mask || !seq_id || !chain_id || !row_cu || !dist_scale || !rot_scale || !out || !scratch)
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: null pointer");
     if (M < 0 || H <= 0 || n_rows < 0 || max_row_len < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: bad sizes");
-    if (ld_out < 3 * H || H > 65535 || n_rows > 65535)
+    const bool small = max_row_len <= 16;
+    if (ld_out < 3 * H || H > 65535 || (!small && n_rows > 65535))
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: ld_out=%d < 3*v_heads=%d or grid too large", ld_out, 3 * H);
     if (M == 0 || n_rows == 0 || max_row_len == 0) return ESMK_OK;
     hipStream_t s = (hipStream_t)stream;
@@ -258,8 +335,24 @@ extern "C" int esmk_geom_attn(const float* proj, const float* affine, const uint
     hipLaunchKernelGGL(geom_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, proj, affine,
                        affine_mask, seq_id, chain_id, dist_scale, rot_scale, qrec, krec, M, H);
     ESMK_CHECK_LAUNCH("esmk_geom_attn(prep)");
-    hipLaunchKernelGGL(geom_attn_kernel, dim3((max_row_len + GQ - 1) / GQ, n_rows, H), dim3(GQ), 0, s, qrec, krec,
-                       affine, affine_mask, seq_id, chain_id, row_cu, (__bf16*)out, ld_out, M, H);
+    const bool zf = mask_and_zero_frameless != 0;
+    if (small) {
+        const dim3 grid((n_rows + 15) / 16, H);
+        if (zf)
+            hipLaunchKernelGGL(geom_attn_small_kernel<true>, grid, dim3(256), 0, s, qrec, krec, affine, affine_mask, seq_id,
+                               chain_id, row_cu, n_rows, (__bf16*)out, ld_out, M, H);
+        else
+            hipLaunchKernelGGL(geom_attn_small_kernel<false>, grid, dim3(256), 0, s, qrec, krec, affine, affine_mask, seq_id,
+                               chain_id, row_cu, n_rows, (__bf16*)out, ld_out, M, H);
+    } else {
+        const dim3 grid((max_row_len + GQ - 1) / GQ, n_rows, H);
+        if (zf)
+            hipLaunchKernelGGL(geom_attn_kernel<true>, grid, dim3(GQ), 0, s, qrec, krec, affine, affine_mask, seq_id,
+                               chain_id, row_cu, (__bf16*)out, ld_out, M, H);
+        else
+            hipLaunchKernelGGL(geom_attn_kernel<false>, grid, dim3(GQ), 0, s, qrec, krec, affine, affine_mask, seq_id,
+                               chain_id, row_cu, (__bf16*)out, ld_out, M, H);
+    }
     ESMK_CHECK_LAUNCH("esmk_geom_attn");
     return ESMK_OK;
 }

@@ -119,6 +119,43 @@ def vqdec_shapes(d: int, n_layers: int):
     return s
 
 
+def vqenc_shapes(d: int, v_heads: int, n_layers: int, d_out: int = 128, n_codes: int = 4096):
+    """StructureTokenEncoder state_dict (esm/models/vqvae.py:179-191; blocks with bias=True, expansion 4)."""
+    h = swiglu_hidden(d, 4)
+    s = {}
+    for i in range(n_layers):
+        p = f"transformer.blocks.{i}."
+        s.update({p + "geom_attn.s_norm.weight": (d,), p + "geom_attn.s_norm.bias": (d,),
+                  p + "geom_attn.proj.weight": (15 * v_heads, d), p + "geom_attn.proj.bias": (15 * v_heads,),
+                  p + "geom_attn.out_proj.weight": (d, 3 * v_heads), p + "geom_attn.out_proj.bias": (d,),
+                  p + "geom_attn.distance_scale_per_head": (v_heads,), p + "geom_attn.rotation_scale_per_head": (v_heads,),
+                  p + "ffn.0.weight": (d,), p + "ffn.0.bias": (d,), p + "ffn.1.weight": (2 * h, d), p + "ffn.1.bias": (2 * h,),
+                  p + "ffn.3.weight": (d, h), p + "ffn.3.bias": (d,)})
+    s.update({"pre_vq_proj.weight": (d_out, d), "pre_vq_proj.bias": (d_out,), "codebook.embeddings": (n_codes, d_out),
+              "codebook.N": (n_codes,), "codebook.z_avg": (n_codes, d_out),
+              "relative_positional_embedding.embedding.weight": (66, d)})
+    return s
+
+
+def vqenc_weights(d: int, v_heads: int, n_layers: int, d_out: int = 128, n_codes: int = 4096, seed: int = 0) -> dict:
+    """Unit-scale weights for the structure encoder: matrices ~ N(0, 1/fan_in), embeddings and codes ~ N(0, 1).  With
+    the N(0, 0.02) matrices used elsewhere the biases swamp the geometry and every residue maps to the same code."""
+    out = {}
+    for name, shape in vqenc_shapes(d, v_heads, n_layers, d_out, n_codes).items():
+        if name.endswith("_scale_per_head"):
+            mean, std = 0.0, 0.5
+        elif ".s_norm." in name or ".ffn.0." in name:
+            mean, std = (1.0, 0.1) if name.endswith("weight") else (0.0, 0.1)
+        elif name.endswith(".bias"):
+            mean, std = 0.0, 0.1
+        elif name.startswith("codebook.") or name.startswith("relative_positional_embedding."):
+            mean, std = 0.0, 1.0
+        else:
+            mean, std = 0.0, float(shape[-1]) ** -0.5
+        out[name] = _draw(name, shape, seed, mean, std)
+    return out
+
+
 def make_weights(shapes: dict, seed: int = 0) -> dict:
     out = {}
     for name, shape in shapes.items():
@@ -157,11 +194,14 @@ def synth_tokens(lengths, pad_to: int | None = None, seed: int = 1234) -> torch.
     return out
 
 
-def synth_backbone(B: int, L: int, seed: int = 7, nan_frac: float = 0.1) -> torch.Tensor:
-    """[B, L, 3, 3] fp32 random-walk backbone (CA step 3.8 A), BOS/EOS rows = inf, nan_frac rows NaN."""
+def synth_backbone(B: int, L: int, seed: int = 7, nan_frac: float = 0.1, jitter: float = 0.0) -> torch.Tensor:
+    """[B, L, 3, 3] fp32 random-walk backbone (CA step 3.8 A), BOS/EOS rows = inf, nan_frac rows NaN.
+    jitter > 0 varies the step length by that fraction (no two CA-CA distances tie: nearest-neighbour order unique)."""
     g = torch.Generator().manual_seed(seed)
     step = torch.randn(B, L, 3, generator=g)
     step = 3.8 * step / step.norm(dim=-1, keepdim=True)
+    if jitter > 0:
+        step = step * (1.0 + jitter * (2 * torch.rand(B, L, 1, generator=torch.Generator().manual_seed(seed + 99991)) - 1))
     ca = torch.cumsum(step, dim=1)
     n = ca + 1.46 * torch.nn.functional.normalize(torch.randn(B, L, 3, generator=g), dim=-1)
     c = ca + 1.52 * torch.nn.functional.normalize(torch.randn(B, L, 3, generator=g), dim=-1)

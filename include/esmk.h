@@ -84,10 +84,12 @@ int esmk_add2_layernorm(float* x, const void* delta_a_bf16, const void* delta_b_
  * Replaces: every nn.Linear on the path (reference attention.py:27,29,82; blocks.py:32-37;
  * geom_attention.py:43,45; regression_head.py:18,21) with the op that follows it fused:
  *   ESMK_EPI_BF16       out bf16 [M,N]            = alpha * acc            (alpha = 1/s makes it a residual delta)
- *   ESMK_EPI_F32        out f32  [M,N]            = acc (+ bias if bias != NULL)
+ *   ESMK_EPI_F32        out f32  [M,N]            = acc
  *   ESMK_EPI_SWIGLU     out bf16 [M,N/2]          = silu(gate) * up       (blocks.py:26-27; W packed SWIGLU)
  *   ESMK_EPI_RESIDUAL   out f32  [M,N] (in/out)   += alpha * acc           (blocks.py:147-155, alpha = 1/s)
  *   ESMK_EPI_BIAS_GELU  out bf16 [M,N]            = gelu_erf(acc + bias)   (regression_head.py:18-19)
+ * bias (f32 [N], 16-byte aligned, reference row order; NULL = none) is added to acc in every epilogue - the
+ * bias=True block variants (blocks.py:81, vqvae.py:154); for SWIGLU it is ffn.1.bias = [gate bias | up bias].
  * A: bf16 row-major with leading dimension lda >= round_up(K,64) (pad columns must be zero or finite:
  * the packed weight is zero there).
  * ------------------------------------------------------------------------------------------ */
@@ -189,6 +191,14 @@ int esmk_geom_attn(const float* proj, const float* affine, const uint8_t* affine
                    const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
                    const float* dist_scale, const float* rot_scale, void* out_bf16, int ld_out, void* scratch,
                    int M, int v_heads, esmk_stream_t stream);
+/* Same with mask_and_zero_frameless selectable (geom_attention.py:36,145-146).  0 is the VQ-VAE structure encoder's
+ * setting (GeometricEncoderStack, vqvae.py:142-159): rows without a frame are not zeroed and a query whose keys are
+ * all masked gets the reference's uniform softmax over its row.  Rows of at most 16 tokens (kNN neighbourhoods) take
+ * a kernel with one thread per (row, slot) and no n_rows limit. */
+int esmk_geom_attn_ex(const float* proj, const float* affine, const uint8_t* affine_mask, const int32_t* seq_id,
+                      const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
+                      const float* dist_scale, const float* rot_scale, void* out_bf16, int ld_out, void* scratch,
+                      int M, int v_heads, int mask_and_zero_frameless, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Whole trunk in one call.  Replaces TransformerStack.forward (reference
@@ -306,6 +316,33 @@ int esmk_categorical_mean(const float* logits, int R, int V, float lo, float hi,
 int esmk_pairwise_pae(const float* qk, const void* w1_bf16, const void* w2_bf16, const float* b2,
                       const uint8_t* aa_mask, int B, int L, float max_bin, float* pae, float* ptm,
                       esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Input side of the VQ-VAE structure encoder (StructureTokenEncoder.encode, reference esm/models/vqvae.py:179-322).
+ * Its GeometricEncoderStack blocks (bias=True, geometric attention only) are composed from esmk_layernorm,
+ * esmk_gemm (bias in every epilogue), esmk_geom_attn_ex and esmk_embed; these two surround them.
+ *
+ * esmk_knn_neighbourhoods: find_knn_edges / knn_graph (vqvae.py:265-289, esm/utils/misc.py:135-174) and the gathers of
+ *   encode_local_structure (vqvae.py:224-248).  Per residue: the `knn` (= min(16, L)) nearest residues of its batch
+ *   row by CA distance; pairs lacking coordinates rank by 1e6 + 100 |i - j|; padded pairs and pairs of different
+ *   sequence_id are +inf; ascending, ties by lower index (torch.sort's order on the CPU).
+ *     coords f32 [B, L, 3, 3] (N, CA, C), coord_mask u8 [B, L] (esmk_frames' mask), padding_mask u8 [B, L] (1 = pad),
+ *     seq_id int32 [B, L] or NULL, residue_index int64 [B, L] or NULL (= position), affine f32 [B*L, 12]
+ *     -> edges int64 [B, L, knn], edge_mask u8 (distance finite), knn_affine f32 [B*L*knn, 12], knn_mask u8,
+ *        knn_seq int32, rel_idx int64 [B*L*knn] = clamp(res[j] - res[0], +-rel_bins) + rel_bins + 1 (vqvae.py:45-48)
+ * esmk_vq_quantize: z = Linear(d, 128)(x rows, zeroed where keep == 0) (vqvae.py:317-318), then EMACodebook.forward
+ *   (esm/layers/codebook.py:57-75): index of the nearest code (first index on ties) and that code.  fp32 throughout.
+ *     x f32, row r at x + r * row_stride (row_stride = 16 d selects each neighbourhood's query node, vqvae.py:260-261)
+ *     w_t f32 [d, 128] = pre_vq_proj.weight^T, bias f32 [128], codes_t f32 [128, n_codes] = embeddings^T,
+ *     code_sq f32 [n_codes] = |code|^2;  z / z_q f32 [M, 128] (either may be NULL), indices int64 [M]
+ * ------------------------------------------------------------------------------------------ */
+int esmk_knn_neighbourhoods(const float* coords, const uint8_t* coord_mask, const uint8_t* padding_mask,
+                            const int32_t* seq_id, const int64_t* residue_index, const float* affine, int B, int L,
+                            int knn, int rel_bins, int64_t* edges, uint8_t* edge_mask, float* knn_affine,
+                            uint8_t* knn_mask, int32_t* knn_seq, int64_t* rel_idx, esmk_stream_t stream);
+int esmk_vq_quantize(const float* x, int row_stride, const uint8_t* keep, const float* w_t, const float* bias,
+                     const float* codes_t, const float* code_sq, int M, int d, int d_code, int n_codes, float* z,
+                     float* z_q, int64_t* indices, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Timing helpers (thin wrappers over hipEvent*, so that a harness without HIP headers can time kernels on

@@ -349,6 +349,56 @@ def sampling_cases():
     save("sampling", **out)
 
 
+def vqenc_case(name, d, VH, NL, n_codes, B, L, wseed, cseed, nan_frac=0.1, pad_from=None, sequence_id=None,
+               residue_index=None):
+    """StructureTokenEncoder.encode end to end (vqvae.py:291-322) + its kNN edges and the pre-quantisation z."""
+    w = synth.vqenc_weights(d, VH, NL, 128, n_codes, seed=wseed)
+    m = ref_import.build_vqenc(d, VH, NL, 128, n_codes, w)
+    coords = synth.synth_backbone(B, L, seed=cseed, nan_frac=nan_frac, jitter=0.15)
+    mask = torch.ones(B, L, dtype=torch.bool)
+    if pad_from is not None:
+        mask[-1, pad_from:] = False
+        coords[-1, pad_from:] = float("nan")
+    zs = []
+    hook = m.pre_vq_proj.register_forward_hook(lambda _m, _i, o: zs.append(o.detach().float().clone()))
+    with torch.no_grad():
+        zq, idx = m.encode(coords, attention_mask=mask, sequence_id=sequence_id, residue_index=residue_index)
+        from esm.utils.structure.affine3d import build_affine3d_from_coordinates
+        _, amask = build_affine3d_from_coordinates(coords)
+        sid = sequence_id if sequence_id is not None else torch.zeros(B, L, dtype=torch.int64)
+        edges, emask = m.find_knn_edges(coords, ~mask, coord_mask=amask, sequence_id=sid, knn=16)
+    arrays = dict(kind="vqenc", d=d, VH=VH, NL=NL, n_codes=n_codes, wseed=wseed, coords=_np(coords), attention_mask=_np(mask),
+                  z_q=_np(zq), indices=_np(idx), z=_np(zs[0]), edges=_np(edges), edge_mask=_np(emask), affine_mask=_np(amask))
+    if sequence_id is not None:
+        arrays["sequence_id"] = _np(sequence_id)
+    if residue_index is not None:
+        arrays["residue_index"] = _np(residue_index)
+    # No bf16 calibration here: the reference's encoder does not run in bf16 on the CPU, with .to(bfloat16) or under
+    # autocast (its rotations are forced to fp32 and then meet bf16 projections: affine3d.py:168-175 raises).
+    hook.remove()
+    # margin of every token: gap between the nearest and the second nearest code (squared distances)
+    flat = zs[0].reshape(-1, zs[0].shape[-1])
+    cb = w["codebook.embeddings"]
+    dist = (flat ** 2).sum(1, keepdim=True) - 2 * flat @ cb.T + (cb.T ** 2).sum(0, keepdim=True)
+    top2 = dist.topk(2, dim=1, largest=False).values
+    arrays["margin"] = _np((top2[:, 1] - top2[:, 0]).reshape(B, L))
+    print(name, "tokens", idx[0, :8].tolist(), "distinct", int(idx[amask].unique().numel()), "of", int(amask.sum()),
+          "| z absmax", float(zs[0].abs().max()), "median margin", float(arrays["margin"][_np(amask)].mean()))
+    save(name, **arrays)
+
+
+def vqenc_cases():
+    vqenc_case("vqenc_tiny", 128, 8, 2, 512, 2, 40, wseed=81, cseed=800, nan_frac=0.15, pad_from=31)
+    sid = torch.zeros(2, 40, dtype=torch.int64)
+    sid[0, 22:] = 1
+    res = torch.arange(40)[None, :].repeat(2, 1)
+    res[:, 20:] += 50  # a numbering gap: relative positions clamp at +-32
+    vqenc_case("vqenc_tiny_seqid_resindex", 128, 8, 2, 512, 2, 40, wseed=81, cseed=801, sequence_id=sid, residue_index=res)
+    vqenc_case("vqenc_tiny_short", 128, 8, 2, 512, 1, 10, wseed=81, cseed=802, nan_frac=0.0)  # L < knn
+    vqenc_case("vqenc_tiny_sparse", 128, 8, 2, 512, 1, 48, wseed=81, cseed=803, nan_frac=0.8)  # few frames: sequence-distance edges
+    vqenc_case("vqenc_d1024_vh128", 1024, 128, 2, 4096, 1, 64, wseed=82, cseed=804, nan_frac=0.1)
+
+
 def vqdec_cases():
     # tiny (2 blocks, d 128) incl. a bin-packed sequence_id, and the released geometry (30 blocks, d 1280, 20 heads)
     vqdec_case("vqdec_tiny", 128, 2, 2, 40, [40, 27], wseed=71, tseed=700)
@@ -373,6 +423,8 @@ def main():
         return stack_case("stack_d1280_vqdec", 1280, 20, 30, 64, wseed=61, scale_residue=False)
     if "--vqdec-model-only" in sys.argv:
         return vqdec_cases()
+    if "--vqenc-only" in sys.argv:
+        return vqenc_cases()
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -426,6 +478,8 @@ def main():
               big_stride=8)
     # (vii) VQ-VAE structure decoder, tokens -> coordinates / pLDDT / pTM / pae
     vqdec_cases()
+    # (viii) VQ-VAE structure encoder, coordinates -> structure tokens
+    vqenc_cases()
 
 
 if __name__ == "__main__":

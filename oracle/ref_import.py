@@ -106,6 +106,16 @@ def build_vqdec(d_model, n_heads, n_layers, weights: dict):
     return m
 
 
+def build_vqenc(d_model, v_heads, n_layers, d_out, n_codes, weights: dict):
+    install()
+    from esm.models.vqvae import StructureTokenEncoder
+
+    m = StructureTokenEncoder(d_model=d_model, n_heads=1, v_heads=v_heads, n_layers=n_layers, d_out=d_out,
+                              n_codes=n_codes).eval()
+    m.load_state_dict(weights, strict=True)
+    return m
+
+
 def build_frames(coords):
     install()
     from esm.utils.structure.affine3d import build_affine3d_from_coordinates

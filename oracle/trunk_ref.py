@@ -95,13 +95,19 @@ def multi_head_attention(x, sequence_id, w, prefix, n_heads):
     return ctx @ w[prefix + "out_proj.weight"].T
 
 
+def _linear(x, w, name):
+    """nn.Linear with an optional bias (the bias=True block variants, blocks.py:81)."""
+    y = x @ w[name + ".weight"].T
+    return y + w[name + ".bias"] if name + ".bias" in w else y
+
+
 def swiglu_ffn(x, w, prefix):
     """esm/layers/blocks.py:15-38."""
     h = layer_norm(x, w[prefix + "0.weight"], w[prefix + "0.bias"])
-    y = h @ w[prefix + "1.weight"].T
+    y = _linear(h, w, prefix + "1")
     hid = y.shape[-1] // 2
     y = F.silu(y[..., :hid]) * y[..., hid:]
-    return y @ w[prefix + "3.weight"].T
+    return _linear(y, w, prefix + "3")
 
 
 def build_frames(coords):
@@ -136,8 +142,10 @@ def build_frames(coords):
     return rot, trans, mask
 
 
-def geometric_attention(s, rot, trans, affine_mask, sequence_id, chain_id, w, prefix, v_heads):
-    """esm/layers/geom_attention.py:52-149 (mask_and_zero_frameless=True, bias=False)."""
+def geometric_attention(s, rot, trans, affine_mask, sequence_id, chain_id, w, prefix, v_heads,
+                        mask_and_zero_frameless=True):
+    """esm/layers/geom_attention.py:52-149; biases of s_norm / proj / out_proj are used when the weight dict has
+    them (bias=True: the VQ-VAE structure encoder, which also sets mask_and_zero_frameless=False)."""
     B, L, d = s.shape
     H = v_heads
     if sequence_id is None:
@@ -147,8 +155,8 @@ def geometric_attention(s, rot, trans, affine_mask, sequence_id, chain_id, w, pr
     bias = bias.masked_fill(~affine_mask[:, None, None, :], fmin)
     bias = bias.masked_fill((chain_id.unsqueeze(1) != chain_id.unsqueeze(2)).unsqueeze(1), fmin)
 
-    ns = layer_norm(s, w[prefix + "s_norm.weight"])
-    proj = ns @ w[prefix + "proj.weight"].T  # [B, L, 15H]
+    ns = layer_norm(s, w[prefix + "s_norm.weight"], w.get(prefix + "s_norm.bias"))
+    proj = _linear(ns, w, prefix + "proj")  # [B, L, 15H]
     vec_rot = proj[..., : 9 * H].reshape(B, L, 3 * H, 3)
     vec_dist = proj[..., 9 * H :].reshape(B, L, 2 * H, 3)
     # R . p for every 3-vector (RotationMatrix.apply, affine3d.py:168-175)
@@ -167,8 +175,9 @@ def geometric_attention(s, rot, trans, affine_mask, sequence_id, chain_id, w, pr
     o = torch.einsum("bhij,bjhc->bihc", p, val)  # [B, L, H, 3] global frame
     o = torch.einsum("blji,blhj->blhi", rot, o)  # R^T . o
     o = o.reshape(B, L, 3 * H)
-    o = o.masked_fill(~affine_mask[..., None], 0.0)
-    return o @ w[prefix + "out_proj.weight"].T
+    if mask_and_zero_frameless:
+        o = o.masked_fill(~affine_mask[..., None], 0.0)
+    return _linear(o, w, prefix + "out_proj")
 
 
 def transformer_block(x, sequence_id, frames, chain_id, w, prefix, n_heads, v_heads, scale, geom):

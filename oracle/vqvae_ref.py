@@ -10,7 +10,7 @@ from __future__ import annotations
 import torch
 import torch.nn.functional as F
 
-from .trunk_ref import layer_norm, transformer_stack
+from .trunk_ref import build_frames, geometric_attention, layer_norm, swiglu_ffn, transformer_stack
 
 BB_COORDINATES = torch.tensor([[0.5256, 1.3612, 0.0], [0.0, 0.0, 0.0], [-1.5251, 0.0, 0.0]])  # constants/physics.py:1-5
 SPECIAL_MIN = 4096  # min(VQVAE_SPECIAL_TOKENS.values()), constants/esm3.py:13-20
@@ -89,3 +89,59 @@ def decode(structure_tokens, w, n_heads, n_layers, sequence_id=None):
     pl = _mlp(x, w, "plddt_head.", ("dense", "norm", "output"))
     v_bins = (torch.arange(pl.shape[-1], dtype=torch.float32) + 0.5) / pl.shape[-1]  # vqvae.py:118-121
     return dict(tensor7_affine=affine, bb_pred=bb, plddt=pl.softmax(-1) @ v_bins, ptm=ptm, predicted_aligned_error=pae)
+
+
+# --------------------------------------------------------------------------------------------------------------
+# structure encoder (vqvae.py:179-322)
+# --------------------------------------------------------------------------------------------------------------
+MAX_SUPPORTED_DISTANCE = 1e6
+
+
+def knn_graph(ca, coord_mask, padding_mask, sequence_id, no_knn):
+    """esm/utils/misc.py:135-174 with a STABLE sort (what torch.sort does on the CPU): ties - equal sequence
+    distances left and right of a residue without coordinates, +inf - keep the lower index first."""
+    L = ca.shape[-2]
+    pair_no_coords = ~(coord_mask[..., None, :] & coord_mask[..., :, None])
+    pad = padding_mask[..., None, :] | padding_mask[..., :, None]
+    pad = pad | (sequence_id.unsqueeze(1) != sequence_id.unsqueeze(2))
+    dists = (ca.unsqueeze(-2) - ca.unsqueeze(-3)).norm(dim=-1)
+    ar = torch.arange(L)
+    seq_d = (ar[:, None] - ar[None, :]).abs().to(dists.dtype) * 1e2 + MAX_SUPPORTED_DISTANCE
+    d = torch.where(pair_no_coords, seq_d, dists).masked_fill(pad, torch.inf)
+    dv, edges = d.sort(dim=-1, stable=True)
+    k = min(no_knn, L)
+    return edges[..., :k], dv[..., :k].isfinite()
+
+
+def encode(coords, w, v_heads, n_layers, attention_mask=None, sequence_id=None, residue_index=None, knn=16, bins=32):
+    """StructureTokenEncoder.encode -> (z_q [B, L, d_out], indices [B, L], z [B, L, d_out] before quantisation)."""
+    coords = coords[..., :3, :]
+    rot, trans, amask = build_frames(coords)
+    B, L = amask.shape
+    if attention_mask is None:
+        attention_mask = torch.ones(B, L, dtype=torch.bool)
+    if sequence_id is None:
+        sequence_id = torch.zeros(B, L, dtype=torch.int64)
+    c = coords.clone().float()
+    c[~amask] = 0
+    edges, _ = knn_graph(c[..., 1, :], amask, ~attention_mask.bool(), sequence_id, knn)
+    E = edges.shape[-1]
+    bi = torch.arange(B)[:, None, None]
+    g = lambda t: t[bi, edges].reshape(B * L, E, *t.shape[2:])  # noqa: E731  node_gather (vqvae.py:175-176)
+    k_rot, k_trans, k_mask, k_seq = g(rot), g(trans), g(amask), g(sequence_id)
+    res = edges.reshape(B * L, E) if residue_index is None else g(residue_index)
+    diff = (res - res[:, :1]).clamp(-bins, bins) + bins + 1  # RelativePositionEmbedding (vqvae.py:45-48)
+    z = w["relative_positional_embedding.embedding.weight"][diff]
+    chain = torch.zeros(B * L, E, dtype=torch.int64)
+    for i in range(n_layers):  # UnifiedTransformerBlock: geometric attention + FFN, scaling factor 1 (blocks.py:146-157)
+        p = f"transformer.blocks.{i}."
+        z = z + geometric_attention(z, k_rot, k_trans, k_mask, k_seq, chain, w, p + "geom_attn.", v_heads,
+                                    mask_and_zero_frameless=False)
+        z = z + swiglu_ffn(z, w, p + "ffn.")
+    z = z[:, 0, :].reshape(B, L, -1).masked_fill(~amask[..., None], 0)
+    z = z @ w["pre_vq_proj.weight"].T + w["pre_vq_proj.bias"]
+    cb = w["codebook.embeddings"]
+    flat = z.reshape(-1, z.shape[-1])
+    dist = (flat ** 2).sum(1, keepdim=True) - 2 * flat @ cb.T + (cb.T ** 2).sum(0, keepdim=True)  # codebook.py:63-67
+    idx = dist.argmin(dim=1).reshape(B, L)
+    return cb[idx], idx, z

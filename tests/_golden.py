@@ -37,6 +37,8 @@ def weights_for(fx):
         return synth.make_weights(shapes, seed=ws)
     if kind == "vqdec":
         return synth.make_weights(synth.vqdec_shapes(d, int(fx["NL"])), seed=ws)
+    if kind == "vqenc":
+        return synth.vqenc_weights(d, int(fx["VH"]), int(fx["NL"]), 128, int(fx["n_codes"]), seed=ws)
     raise ValueError(kind)
 
 
@@ -47,3 +49,26 @@ def cosine_min(a, b):
     num = (a * b).sum(-1)
     den = a.norm(dim=-1) * b.norm(dim=-1)
     return float((num / den.clamp_min(1e-30)).min())
+
+
+def assert_knn_equal(edges, edge_mask, fx):
+    """kNN edges against a vqenc fixture.  Exact where the reference's order is determined: for a residue WITH
+    coordinates, the leading neighbours that have coordinates too (true CA distances, all distinct in the fixtures).
+    Behind them come residues ranked by sequence distance, where i-k and i+k tie and the reference's unstable
+    torch.sort leaves the order to the platform; there (and for residues without coordinates, whose output is zeroed)
+    only the finite-distance mask and the multiset of sequence distances must agree."""
+    ref_e, ref_m = t(fx["edges"]), t(fx["edge_mask"])
+    amask = t(fx["affine_mask"])
+    assert edges.shape == ref_e.shape and torch.equal(edge_mask.bool(), ref_m)
+    B, L, E = ref_e.shape
+    for b in range(B):
+        for i in range(L):
+            got, want = edges[b, i], ref_e[b, i]
+            if amask[b, i]:
+                n_lead = 0
+                while n_lead < E and ref_m[b, i, n_lead] and amask[b, want[n_lead]]:
+                    n_lead += 1
+                assert torch.equal(got[:n_lead], want[:n_lead]), (b, i)
+                assert int(got[0]) == i
+            fin = ref_m[b, i]
+            assert torch.equal((got[fin] - i).abs().sort().values, (want[fin] - i).abs().sort().values), (b, i)

@@ -90,3 +90,26 @@ def test_vqvae_structure_decoder(name):
     out = vqvae_ref.decode(G.t(fx["tokens"]), w, int(fx["H"]), int(fx["NL"]), sequence_id=sid)
     for k in VQDEC_KEYS:
         _close(out[k], G.t(fx[k]), 1e-4 if name == "vqdec_d1280_30l" else TOL)
+
+
+VQENC = ["vqenc_tiny", "vqenc_tiny_seqid_resindex", "vqenc_tiny_short", "vqenc_tiny_sparse", "vqenc_d1024_vh128"]
+
+
+@pytest.mark.parametrize("name", VQENC)
+def test_vqvae_structure_encoder(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    opt = lambda k: G.t(fx[k]) if k in fx else None  # noqa: E731
+    coords, amask = G.t(fx["coords"]), G.t(fx["affine_mask"])
+    sid = opt("sequence_id")
+    # the kNN graph alone (find_knn_edges)
+    c = coords.clone()
+    c[~amask] = 0
+    edges, emask = vqvae_ref.knn_graph(c[..., 1, :], amask, ~G.t(fx["attention_mask"]),
+                                       sid if sid is not None else torch.zeros(amask.shape, dtype=torch.int64), 16)
+    G.assert_knn_equal(edges, emask, fx)
+    zq, idx, z = vqvae_ref.encode(coords, w, int(fx["VH"]), int(fx["NL"]), attention_mask=G.t(fx["attention_mask"]),
+                                  sequence_id=sid, residue_index=opt("residue_index"))
+    _close(z, G.t(fx["z"]), 1e-4)
+    assert torch.equal(idx, G.t(fx["indices"]))
+    _close(zq, G.t(fx["z_q"]), 1e-6)
