@@ -329,9 +329,9 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         const int ov = gemm_tile_override();
         // measured crossover (tools/gemm_bench.py, M = 512 ... 32768): the 256-tile kernel wins once there are
         // about half as many 256x256 tiles as CUs; below that the 128-tile kernel fills the chip better.
-        // a bias with the bf16 / SwiGLU epilogues (bias=True block variants: VQ-VAE structure encoder) is applied by
-        // the 128-tile kernel and the split-K reduce only; those stacks are small
-        const bool bias128 = bias && (epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU);
+        // a bias with the bf16 epilogue (bias=True block variants) is applied by the 128-tile kernel and the split-K
+        // reduce only (the 256-tile kernel has biased instantiations of its other epilogues)
+        const bool bias128 = bias && epilogue == ESMK_EPI_BF16;
         const bool big = !bias128 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
         // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
         static int use288 = -1;

@@ -50,11 +50,15 @@ __device__ unsigned long long g_stamps[8 * 64];
     } while (0)
 #endif
 
-template <int EPI>
+constexpr int EPI_SWIGLU_BIAS = 102;  // internal: ESMK_EPI_SWIGLU with ffn.1.bias; its own instantiation, so the
+                                      // bias-free kernel of the ESM C / ESM3 trunks is unchanged
+template <int EPI_>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ A, int lda,
                                                          const __bf16* __restrict__ W, int ldw, int M, int N,
                                                          int ktiles, const float* __restrict__ bias, float alpha,
                                                          void* __restrict__ out, int n_ctile, int nblk, int gt) {
+    constexpr bool kSwigluBias = (EPI_ == EPI_SWIGLU_BIAS);
+    constexpr int EPI = kSwigluBias ? ESMK_EPI_SWIGLU : EPI_;
 #ifdef ESMK_GEMM_DBG
     constexpr int dbg = ESMK_GEMM_DBG;  // diagnostic builds only: 1 = no DMA, 2 = no LDS reads, 4 = no epilogue
 #else
@@ -263,7 +267,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
                     if constexpr (EPI == ESMK_EPI_SWIGLU) {
 #pragma unroll
                         for (int mi = 0; mi < 4; mi += 2) {
-                            const f32x4 g = acc[qm][qn][mi][ni], u = acc[qm][qn][mi + 1][ni];
+                            f32x4 g = acc[qm][qn][mi][ni], u = acc[qm][qn][mi + 1][ni];
+                            if constexpr (kSwigluBias) {
+                                const int c = ((c0 + wm * 128) >> 1) + qm * 32 + (mi >> 1) * 16 + q4;  // output channel
+                                if (c < OW) {
+                                    g += *(const f32x4*)(bias + c);
+                                    u += *(const f32x4*)(bias + OW + c);
+                                }
+                            }
                             u32x2 v;
                             v.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
                             v.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
@@ -315,7 +326,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
 #pragma unroll
                     for (int mi = 0; mi < 4; mi += 2)
                         epi_swiglu4(acc[qm][qn][mi][ni], acc[qm][qn][mi + 1][ni], t, (cb >> 1) + (mi >> 1) * 16 + q4,
-                                    N >> 1, out);
+                                    N >> 1, out, kSwigluBias ? bias : nullptr);
                 } else {
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
@@ -355,7 +366,9 @@ int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int
     switch (epilogue) {
         case ESMK_EPI_BF16: return launch<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         case ESMK_EPI_F32: return launch<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
-        case ESMK_EPI_SWIGLU: return launch<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+        case ESMK_EPI_SWIGLU:
+            if (bias) return launch<EPI_SWIGLU_BIAS>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
+            return launch<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         case ESMK_EPI_RESIDUAL: return launch<ESMK_EPI_RESIDUAL>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         case ESMK_EPI_BIAS_GELU: return launch<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);

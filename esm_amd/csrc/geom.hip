@@ -229,28 +229,59 @@ __global__ __launch_bounds__(GQ) void geom_attn_kernel(const float* __restrict__
     o[2] = (__bf16)(R[2] * ox + R[5] * oy + R[8] * oz);
 }
 
-// Rows of at most 16 tokens (the structure encoder's kNN neighbourhoods, vqvae.py:193-263): 16 rows per 256-thread
-// block, one thread per (row, slot); the <= 16 keys of a row are read straight from the K records (the 16 threads
-// of a row read the same addresses - one broadcast load each).
+// Rows of at most 16 tokens (the structure encoder's kNN neighbourhoods, vqvae.py:193-263): prep and attention in
+// ONE kernel, no Q/K records in HBM.  A block is one row x 16 heads: thread (slot, hh) rotates its token's five
+// projected vectors of head hh into the global frame (consecutive hh read consecutive 12-byte vectors of the
+// projection), parks the key / value part in LDS and then runs the <= 16-key softmax of its query from there.
+constexpr int SK_STRIDE = 16 * 12 + 4;  // floats per head in LDS (+4: spreads the 16 heads over the banks)
+
 template <bool ZF>
-__global__ __launch_bounds__(256) void geom_attn_small_kernel(const float* __restrict__ qrec, const float* __restrict__ krec,
+__global__ __launch_bounds__(256) void geom_attn_small_kernel(const float* __restrict__ proj,
                                                               const float* __restrict__ affine,
                                                               const uint8_t* __restrict__ amask,
                                                               const int* __restrict__ seq_id,
                                                               const int* __restrict__ chain_id,
-                                                              const int* __restrict__ row_cu, int n_rows,
-                                                              __bf16* __restrict__ out, int ld_out, int M, int H) {
-    const int row = blockIdx.x * 16 + (threadIdx.x >> 4), h = blockIdx.y;
-    if (row >= n_rows) return;
-    const int r0 = row_cu[row], r1 = row_cu[row + 1];
-    const int qi = r0 + (threadIdx.x & 15);
-    if (qi >= r1) return;
-    const float* q = qrec + ((size_t)h * M + qi) * 8;
-    const f32x4 qa = *(const f32x4*)q, qb = *(const f32x4*)(q + 4);
-    const int my_seq = seq_id[qi], my_chain = chain_id[qi];
+                                                              const int* __restrict__ row_cu,
+                                                              const float* __restrict__ dist_scale,
+                                                              const float* __restrict__ rot_scale,
+                                                              __bf16* __restrict__ out, int ld_out, int H) {
+    __shared__ __attribute__((aligned(16))) float ks[16 * SK_STRIDE];
+    const int slot = threadIdx.x >> 4, hh = threadIdx.x & 15;
+    const int h = blockIdx.y * 16 + hh;
+    const int r0 = row_cu[blockIdx.x], r1 = row_cu[blockIdx.x + 1];
+    const int t = r0 + slot;
+    const bool active = t < r1 && h < H;
+    float R[9];
+    f32x4 qa = f32x4{0.f, 0.f, 0.f, 0.f}, qb = qa;
+    int my_seq = 0, my_chain = 0;
+    float* kd_ = ks + hh * SK_STRIDE + slot * 12;
+    if (active) {
+        const float* A = affine + (size_t)t * 12;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = A[k];
+        const V3 T{A[9], A[10], A[11]};
+        const float* p = proj + (size_t)t * 15 * H;
+        auto vec = [&](int v) { return V3{p[v * 3], p[v * 3 + 1], p[v * 3 + 2]}; };
+        const float cr = softplus(rot_scale[h]) * (LOG2E * 0.57735026918962576f);
+        const float cd = softplus(dist_scale[h]) * (LOG2E * 0.57735026918962576f);
+        const V3 qr = rot_apply(R, vec(h)), kr = rot_apply(R, vec(H + h)), vv = rot_apply(R, vec(2 * H + h));
+        V3 qd = rot_apply(R, vec(3 * H + h)), kd = rot_apply(R, vec(4 * H + h));
+        qd = {qd.x + T.x, qd.y + T.y, qd.z + T.z};
+        kd = {kd.x + T.x, kd.y + T.y, kd.z + T.z};
+        qa = f32x4{qr.x * cr, qr.y * cr, qr.z * cr, qd.x * cd};
+        qb = f32x4{qd.y * cd, qd.z * cd, 0.f, 0.f};
+        my_seq = seq_id[t];
+        my_chain = chain_id[t];
+        *(f32x4*)kd_ = f32x4{kr.x, kr.y, kr.z, kd.x * cd};
+        *(f32x4*)(kd_ + 4) = f32x4{kd.y * cd, kd.z * cd, vv.x, vv.y};
+        *(f32x4*)(kd_ + 8) = f32x4{vv.z, amask[t] ? 1.f : 0.f, __int_as_float(my_seq), __int_as_float(my_chain)};
+    }
+    __syncthreads();
+    if (!active) return;
+    const int nk = r1 - r0;
     float m = -FLT_MAX, l = 0.f, ox = 0.f, oy = 0.f, oz = 0.f, ux = 0.f, uy = 0.f, uz = 0.f;
-    for (int k = r0; k < r1; ++k) {
-        const float* kp = krec + ((size_t)h * M + k) * 12;
+    for (int k = 0; k < nk; ++k) {
+        const float* kp = ks + hh * SK_STRIDE + k * 12;
         const f32x4 ka = *(const f32x4*)kp, kb = *(const f32x4*)(kp + 4), kc = *(const f32x4*)(kp + 8);
         const bool ok = (kc[1] != 0.f) && (__float_as_int(kc[3]) == my_chain);
         const float dx = qa[3] - ka[3], dy = qb[0] - kb[0], dz = qb[1] - kb[1];
@@ -263,26 +294,25 @@ __global__ __launch_bounds__(256) void geom_attn_small_kernel(const float* __res
                 l *= a; ox *= a; oy *= a; oz *= a;
                 m = s;
             }
-            const float p = __builtin_amdgcn_exp2f(s - m);
-            l += p;
-            ox += p * kb[2];
-            oy += p * kb[3];
-            oz += p * kc[0];
+            const float pw = __builtin_amdgcn_exp2f(s - m);
+            l += pw;
+            ox += pw * kb[2];
+            oy += pw * kb[3];
+            oz += pw * kc[0];
         }
     }
-    __bf16* o = out + (size_t)qi * ld_out + h * 3;
+    __bf16* o = out + (size_t)t * ld_out + h * 3;
     if constexpr (ZF) {
-        if (amask[qi] == 0 || l == 0.f) {
+        if (amask[t] == 0 || l == 0.f) {
             o[0] = (__bf16)0.f; o[1] = (__bf16)0.f; o[2] = (__bf16)0.f;
             return;
         }
     } else if (l == 0.f) {
-        l = (float)(r1 - r0); ox = ux; oy = uy; oz = uz;
+        l = (float)nk; ox = ux; oy = uy; oz = uz;
     }
     const float inv = 1.0f / l;
     ox *= inv; oy *= inv; oz *= inv;
-    const float* R = affine + (size_t)qi * 12;
-    o[0] = (__bf16)(R[0] * ox + R[3] * oy + R[6] * oz);
+    o[0] = (__bf16)(R[0] * ox + R[3] * oy + R[6] * oz);  // inverse rotation = R^T . o
     o[1] = (__bf16)(R[1] * ox + R[4] * oy + R[7] * oz);
     o[2] = (__bf16)(R[2] * ox + R[5] * oy + R[8] * oz);
 }
@@ -317,7 +347,8 @@ extern "C" int esmk_geom_attn_ex(const float* proj, const float* affine, const u
                                  int max_row_len, const float* dist_scale, const float* rot_scale, void* out, int ld_out,
                                  void* scratch, int M, int H, int mask_and_zero_frameless, esmk_stream_t stream) {
     if (M == 0 || n_rows == 0 || max_row_len == 0) return ESMK_OK;
-    if (!proj || !affine || !affine_mask || !seq_id || !chain_id || !row_cu || !dist_scale || !rot_scale || !out || !scratch)
+    if (!proj || !affine || !affine_mask || !seq_id || !chain_id || !row_cu || !dist_scale || !rot_scale || !out ||
+        (!scratch && max_row_len > 16))
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: null pointer");
     if (M < 0 || H <= 0 || n_rows < 0 || max_row_len < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_geom_attn: bad sizes");
     const bool small = max_row_len <= 16;
@@ -331,20 +362,23 @@ extern "C" int esmk_geom_attn_ex(const float* proj, const float* affine, const u
         if (hipMemsetAsync(out, 0, (size_t)M * ld_out * 2, s) != hipSuccess)
             ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_geom_attn: memset failed");
     }
+    const bool zf = mask_and_zero_frameless != 0;
+    if (small) {  // fused prep + attention, no scratch
+        const dim3 grid(n_rows, (H + 15) / 16);
+        if (zf)
+            hipLaunchKernelGGL(geom_attn_small_kernel<true>, grid, dim3(256), 0, s, proj, affine, affine_mask, seq_id, chain_id,
+                               row_cu, dist_scale, rot_scale, (__bf16*)out, ld_out, H);
+        else
+            hipLaunchKernelGGL(geom_attn_small_kernel<false>, grid, dim3(256), 0, s, proj, affine, affine_mask, seq_id, chain_id,
+                               row_cu, dist_scale, rot_scale, (__bf16*)out, ld_out, H);
+        ESMK_CHECK_LAUNCH("esmk_geom_attn(small rows)");
+        return ESMK_OK;
+    }
     const size_t total = (size_t)M * H;
     hipLaunchKernelGGL(geom_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, proj, affine,
                        affine_mask, seq_id, chain_id, dist_scale, rot_scale, qrec, krec, M, H);
     ESMK_CHECK_LAUNCH("esmk_geom_attn(prep)");
-    const bool zf = mask_and_zero_frameless != 0;
-    if (small) {
-        const dim3 grid((n_rows + 15) / 16, H);
-        if (zf)
-            hipLaunchKernelGGL(geom_attn_small_kernel<true>, grid, dim3(256), 0, s, qrec, krec, affine, affine_mask, seq_id,
-                               chain_id, row_cu, n_rows, (__bf16*)out, ld_out, M, H);
-        else
-            hipLaunchKernelGGL(geom_attn_small_kernel<false>, grid, dim3(256), 0, s, qrec, krec, affine, affine_mask, seq_id,
-                               chain_id, row_cu, n_rows, (__bf16*)out, ld_out, M, H);
-    } else {
+    {
         const dim3 grid((max_row_len + GQ - 1) / GQ, n_rows, H);
         if (zf)
             hipLaunchKernelGGL(geom_attn_kernel<true>, grid, dim3(GQ), 0, s, qrec, krec, affine, affine_mask, seq_id,

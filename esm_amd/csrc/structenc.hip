@@ -91,6 +91,8 @@ __global__ __launch_bounds__(256) void knn_kernel(const float* __restrict__ coor
 
 // ------------------------------------------------------------------------------------------------------------
 // 16 tokens per block.  x rows are taken with a stride (the query node is row 0 of each neighbourhood).
+// fp32 FMAs on the vector ALUs; every LDS read is a 16-byte broadcast that feeds 16 (projection) or 64 (code search)
+// FMAs, so one wave per SIMD (the tile takes 100 KB of LDS) still keeps its ALU busy.
 constexpr int VQ_TOK = 16;
 
 __global__ __launch_bounds__(256) void vq_quantize_kernel(const float* __restrict__ x, size_t row_stride,
@@ -102,10 +104,11 @@ __global__ __launch_bounds__(256) void vq_quantize_kernel(const float* __restric
                                                           int n_codes, float* __restrict__ z_out,
                                                           float* __restrict__ zq_out, int64_t* __restrict__ idx_out) {
     constexpr int DZ = 128;
-    extern __shared__ float smem[];
-    float* xs = smem;                       // [VQ_TOK][d]
-    float* zs = smem + (size_t)VQ_TOK * d;  // [VQ_TOK][DZ]
-    float* bestv = zs + VQ_TOK * DZ;        // [VQ_TOK][256]
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* xs = smem;                        // [VQ_TOK][d]
+    float* zsT = smem + (size_t)VQ_TOK * d;  // [DZ][VQ_TOK]
+    float* part = zsT + DZ * VQ_TOK;         // [VQ_TOK][DZ] partial sums of the upper k half; later bestv [VQ_TOK][256]
+    float* bestv = part;
     int* besti = (int*)(bestv + VQ_TOK * 256);
     const int tid = threadIdx.x;
     const int t0 = blockIdx.x * VQ_TOK;
@@ -117,22 +120,37 @@ __global__ __launch_bounds__(256) void vq_quantize_kernel(const float* __restric
         xs[e] = v;
     }
     __syncthreads();
-    {   // z = x . W^T + b : thread = (channel c, 8 tokens)
-        const int c = tid & (DZ - 1), tg = (tid >> 7) * 8;
-        float acc[8];
+    {   // z = x . W^T + b : thread = (channel c, half of k), all 16 tokens; d % 8 == 0
+        const int c = tid & (DZ - 1), kh = tid >> 7;
+        const int k0 = kh * (d >> 1), k1 = k0 + (d >> 1);
+        float acc[VQ_TOK];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc[u] = 0.f;
-        for (int k = 0; k < d; ++k) {
-            const float wv = wT[(size_t)k * DZ + c];
+        for (int t = 0; t < VQ_TOK; ++t) acc[t] = 0.f;
+#pragma unroll 4
+        for (int k = k0; k < k1; k += 4) {
+            float wv[4];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) acc[u] = fmaf(xs[(tg + u) * d + k], wv, acc[u]);
+            for (int u = 0; u < 4; ++u) wv[u] = wT[(size_t)(k + u) * DZ + c];
+#pragma unroll
+            for (int t = 0; t < VQ_TOK; ++t) {
+                const f32x4 xv = *(const f32x4*)(xs + t * d + k);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[t] = fmaf(xv[u], wv[u], acc[t]);
+            }
         }
-        const float bv = bias[c];
+        if (kh == 1) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float z = acc[u] + bv;
-            zs[(tg + u) * DZ + c] = z;
-            if (t0 + tg + u < M && z_out) z_out[(size_t)(t0 + tg + u) * DZ + c] = z;
+            for (int t = 0; t < VQ_TOK; ++t) part[t * DZ + c] = acc[t];
+        }
+        __syncthreads();
+        if (kh == 0) {
+            const float bv = bias[c];
+#pragma unroll
+            for (int t = 0; t < VQ_TOK; ++t) {
+                const float z = (acc[t] + part[t * DZ + c]) + bv;
+                zsT[c * VQ_TOK + t] = z;
+                if (t0 + t < M && z_out) z_out[(size_t)(t0 + t) * DZ + c] = z;
+            }
         }
     }
     __syncthreads();
@@ -141,22 +159,43 @@ __global__ __launch_bounds__(256) void vq_quantize_kernel(const float* __restric
     int bi[VQ_TOK];
 #pragma unroll
     for (int t = 0; t < VQ_TOK; ++t) { bv[t] = INFINITY; bi[t] = 0x7fffffff; }
-    for (int code = tid; code < n_codes; code += 256) {
-        float acc[VQ_TOK];
+    for (int code0 = tid; code0 < n_codes; code0 += 1024) {  // this thread: codes code0 + 256 u, ascending
+        float acc[4][VQ_TOK];
 #pragma unroll
-        for (int t = 0; t < VQ_TOK; ++t) acc[t] = 0.f;
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int t = 0; t < VQ_TOK; ++t) acc[u][t] = 0.f;
+#pragma unroll 8  // 32 independent global loads in flight per wave: the loop is load-latency bound otherwise
         for (int c = 0; c < DZ; ++c) {
-            const float ev = codesT[(size_t)c * n_codes + code];
+            float ev[4];
 #pragma unroll
-            for (int t = 0; t < VQ_TOK; ++t) acc[t] = fmaf(zs[t * DZ + c], ev, acc[t]);
+            for (int u = 0; u < 4; ++u) {
+                const int code = code0 + 256 * u;
+                ev[u] = code < n_codes ? codesT[(size_t)c * n_codes + code] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 zv = *(const f32x4*)(zsT + c * VQ_TOK + 4 * q);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[u][4 * q + j] = fmaf(zv[j], ev[u], acc[u][4 * q + j]);
+            }
         }
-        const float sq = code_sq[code];
 #pragma unroll
-        for (int t = 0; t < VQ_TOK; ++t) {
-            const float dd = sq - 2.0f * acc[t];
-            if (dd < bv[t]) { bv[t] = dd; bi[t] = code; }  // codes visited in ascending order per thread
+        for (int u = 0; u < 4; ++u) {
+            const int code = code0 + 256 * u;
+            if (code < n_codes) {
+                const float sq = code_sq[code];
+#pragma unroll
+                for (int t = 0; t < VQ_TOK; ++t) {
+                    const float dd = sq - 2.0f * acc[u][t];
+                    if (dd < bv[t]) { bv[t] = dd; bi[t] = code; }
+                }
+            }
         }
     }
+    __syncthreads();  // part / bestv share LDS
 #pragma unroll
     for (int t = 0; t < VQ_TOK; ++t) { bestv[t * 256 + tid] = bv[t]; besti[t * 256 + tid] = bi[t]; }
     __syncthreads();
@@ -210,7 +249,8 @@ extern "C" int esmk_vq_quantize(const float* x, int row_stride, const uint8_t* k
                                 float* z, float* z_q, int64_t* indices, esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;
     if (!x || !w_t || !bias || !codes_t || !code_sq || !indices) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_vq_quantize: null pointer");
-    if (M < 0 || d <= 0 || n_codes <= 0 || row_stride < d) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_vq_quantize: bad sizes");
+    if (M < 0 || d <= 0 || (d & 7) || n_codes <= 0 || row_stride < d || (row_stride & 3) || ((uintptr_t)x & 15))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_vq_quantize: need d %% 8 == 0, row_stride >= d and %% 4 == 0, x 16-byte aligned");
     if (d_code != 128) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_vq_quantize: code dimension must be 128 (got %d)", d_code);
     const size_t smem = ((size_t)VQ_TOK * d + VQ_TOK * 128 + 2 * VQ_TOK * 256) * sizeof(float);
     if (smem > 160 * 1024) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_vq_quantize: d=%d too wide for the LDS tile", d);

@@ -341,13 +341,12 @@ class StructureTokenEncoder(nn.Module):
             proj = torch.empty((M, 15 * H), dtype=torch.float32, device=dev)
             go = torch.empty((M, ldg), dtype=torch.bfloat16, device=dev)
             hb = torch.empty((M, self.ffn_hidden), dtype=torch.bfloat16, device=dev)
-            scratch = torch.empty(lib.esmk_geom_scratch_bytes(M, H), dtype=torch.uint8, device=dev)
             s = _stream()
             for ly in e["layers"]:
                 L.check(lib.esmk_layernorm(L.ptr(x), L.F32, L.ptr(ly["sn_g"]), L.ptr(ly["sn_b"]), L.ptr(xb), L.BF16, M, d, 1e-5, s), "esmk_layernorm")
                 L.check(lib.esmk_gemm(L.ptr(xb), d, L.ptr(ly["w_proj"]), M, 15 * H, d, L.EPI_F32, L.ptr(ly["b_proj"]), 1.0, L.ptr(proj), s), "esmk_gemm")
                 L.check(lib.esmk_geom_attn_ex(L.ptr(proj), L.ptr(k_aff), L.ptr(k_mask), L.ptr(k_seq), L.ptr(chain), L.ptr(row_cu),
-                                              R, E, L.ptr(ly["dist"]), L.ptr(ly["rot"]), L.ptr(go), ldg, L.ptr(scratch), M, H, 0, s),
+                                              R, E, L.ptr(ly["dist"]), L.ptr(ly["rot"]), L.ptr(go), ldg, None, M, H, 0, s),
                         "esmk_geom_attn_ex")
                 L.check(lib.esmk_gemm(L.ptr(go), ldg, L.ptr(ly["w_out"]), M, d, 3 * H, L.EPI_RESIDUAL, L.ptr(ly["b_out"]), 1.0, L.ptr(x), s), "esmk_gemm")
                 L.check(lib.esmk_layernorm(L.ptr(x), L.F32, L.ptr(ly["ln_g"]), L.ptr(ly["ln_b"]), L.ptr(xb), L.BF16, M, d, 1e-5, s), "esmk_layernorm")

@@ -193,8 +193,8 @@ int esmk_geom_attn(const float* proj, const float* affine, const uint8_t* affine
                    int M, int v_heads, esmk_stream_t stream);
 /* Same with mask_and_zero_frameless selectable (geom_attention.py:36,145-146).  0 is the VQ-VAE structure encoder's
  * setting (GeometricEncoderStack, vqvae.py:142-159): rows without a frame are not zeroed and a query whose keys are
- * all masked gets the reference's uniform softmax over its row.  Rows of at most 16 tokens (kNN neighbourhoods) take
- * a kernel with one thread per (row, slot) and no n_rows limit. */
+ * all masked gets the reference's uniform softmax over its row.  When max_row_len <= 16 (kNN neighbourhoods) one fused
+ * kernel does the frame transforms and the attention: no n_rows limit, and scratch is unused (may be NULL). */
 int esmk_geom_attn_ex(const float* proj, const float* affine, const uint8_t* affine_mask, const int32_t* seq_id,
                       const int32_t* chain_id, const int32_t* row_cu, int n_rows, int max_row_len,
                       const float* dist_scale, const float* rot_scale, void* out_bf16, int ld_out, void* scratch,
