@@ -61,6 +61,7 @@ SIGNATURES = {
     "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),
     "esmk_attn_varlen": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
+    "esmk_attn_l64_d128": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_embed": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, vp]),
     "esmk_esm3_encode": (C.c_int, [C.POINTER(EsmkEsm3Encoder), vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, vp]),
     "esmk_frames": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp]),
@@ -78,6 +79,8 @@ SIGNATURES = {
     "esmk_pairwise_pae": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "esmk_head_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_head_forward": (C.c_int, [C.POINTER(EsmkHead), vp, vp, C.c_int, C.c_int, vp, C.c_size_t, vp]),
+    "esmk_head_ex_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
+    "esmk_head_forward_ex": (C.c_int, [C.POINTER(EsmkHead), vp, vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]),
     "esmk_event_create": (C.c_int, [C.POINTER(vp)]),
     "esmk_event_destroy": (C.c_int, [vp]),
     "esmk_event_record": (C.c_int, [vp, vp]),

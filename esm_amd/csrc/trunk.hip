@@ -215,6 +215,42 @@ extern "C" int esmk_head_forward(const esmk_head* hd, const float* x_norm, float
     return ESMK_OK;
 }
 
+// RegressionHead with hidden_dim != d_model (regression_head.py:4-22; the function decoder's heads use 4 d).
+static size_t head_ex_splitk_bytes(int M, int d, int hidden, int out_dim) {
+    const size_t a = esmk_gemm_workspace_bytes(M, hidden, d), b = esmk_gemm_workspace_bytes(M, out_dim, hidden);
+    return a > b ? a : b;
+}
+
+extern "C" size_t esmk_head_ex_workspace_bytes(int n_tokens, int d_model, int hidden_dim, int out_dim) {
+    if (n_tokens <= 0 || d_model <= 0 || hidden_dim <= 0 || out_dim <= 0) return 0;
+    return align256((size_t)n_tokens * d_model * 2) + 2 * align256((size_t)n_tokens * hidden_dim * 2) +
+           align256(head_ex_splitk_bytes(n_tokens, d_model, hidden_dim, out_dim));
+}
+
+extern "C" int esmk_head_forward_ex(const esmk_head* hd, const float* x, float* logits, int M, int d, int hidden,
+                                    void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (!hd || !x || !logits || !hd->w0 || !hd->b0 || !hd->ln_g || !hd->ln_b || !hd->w3 || !hd->b3)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward_ex: null pointer");
+    if (M < 0 || d <= 0 || (d % 64) || hidden <= 0 || (hidden % 64) || hd->out_dim <= 0)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_head_forward_ex: bad sizes (d and hidden must be multiples of 64)");
+    const size_t need = esmk_head_ex_workspace_bytes(M, d, hidden, hd->out_dim);
+    if (!workspace || workspace_bytes < need)
+        ESMK_FAIL(ESMK_ERR_WORKSPACE, "esmk_head_forward_ex: workspace %zu < required %zu", workspace_bytes, need);
+    char* ws = (char*)workspace;
+    const size_t sx = align256((size_t)M * d * 2), sh = align256((size_t)M * hidden * 2);
+    void* xb = ws;
+    void* h0 = ws + sx;
+    void* h1 = ws + sx + sh;
+    void* skp = ws + sx + 2 * sh;
+    const size_t skb = head_ex_splitk_bytes(M, d, hidden, hd->out_dim);
+    TRY(esmk_cast_f32_bf16(x, xb, (size_t)M * d, (hipStream_t)stream));
+    TRY(esmk_gemm_ws(xb, d, hd->w0, M, hidden, d, ESMK_EPI_BIAS_GELU, hd->b0, 1.f, h0, skp, skb, stream));
+    TRY(esmk_layernorm(h0, ESMK_BF16, hd->ln_g, hd->ln_b, h1, ESMK_BF16, M, hidden, 1e-5f, stream));
+    TRY(esmk_gemm_ws(h1, hidden, hd->w3, M, hd->out_dim, hidden, ESMK_EPI_F32, hd->b3, 1.f, logits, skp, skb, stream));
+    return ESMK_OK;
+}
+
 namespace {
 __global__ void cast_kernel(const float* __restrict__ in, __bf16* __restrict__ out, size_t n4) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

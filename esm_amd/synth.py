@@ -156,6 +156,37 @@ def vqenc_weights(d: int, v_heads: int, n_layers: int, d_out: int = 128, n_codes
     return out
 
 
+def fdec_weights(d: int, n_layers: int, n_keywords: int, n_interpro: int, seed: int = 0) -> dict:
+    """FunctionTokenDecoder state_dict (esm/models/function_decoder.py:85-125), unit-scale like vqenc_weights."""
+    h = 4 * d
+    shapes = {"embedding.weight": (128, d), "decoder.norm.weight": (d,)}
+    for i in range(n_layers):
+        p = f"decoder.blocks.{i}."
+        shapes.update({p + "attn.layernorm_qkv.0.weight": (d,), p + "attn.layernorm_qkv.0.bias": (d,),
+                       p + "attn.layernorm_qkv.1.weight": (3 * d, d), p + "attn.layernorm_qkv.1.bias": (3 * d,),
+                       p + "attn.out_proj.weight": (d, d), p + "attn.out_proj.bias": (d,),
+                       p + "ffn.0.weight": (d,), p + "ffn.0.bias": (d,), p + "ffn.1.weight": (h, d), p + "ffn.1.bias": (h,),
+                       p + "ffn.3.weight": (d, h), p + "ffn.3.bias": (d,)})
+    for name, out in (("keyword_logits", n_keywords), ("keyword_tfidf", n_keywords), ("interpro_logits", n_interpro)):
+        p = f"heads.{name}."
+        shapes.update({p + "0.weight": (h, d), p + "0.bias": (h,), p + "2.weight": (h,), p + "2.bias": (h,),
+                       p + "3.weight": (out, h), p + "3.bias": (out,)})
+    out = {}
+    for name, shape in shapes.items():
+        is_ln = name.endswith("norm.weight") or ".layernorm_qkv.0." in name or ".ffn.0." in name or \
+            (name.startswith("heads.") and ".2." in name)
+        if is_ln:
+            mean, std = (1.0, 0.1) if name.endswith("weight") else (0.0, 0.1)
+        elif name.endswith(".bias"):
+            mean, std = 0.0, 0.1
+        elif name == "embedding.weight":
+            mean, std = 0.0, 1.0
+        else:
+            mean, std = 0.0, float(shape[-1]) ** -0.5
+        out[name] = _draw(name, shape, seed, mean, std)
+    return out
+
+
 def make_weights(shapes: dict, seed: int = 0) -> dict:
     out = {}
     for name, shape in shapes.items():

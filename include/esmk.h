@@ -139,6 +139,14 @@ int esmk_attn_plan(const int32_t* cu_seqlens_host, int n_segments, int32_t* qblk
 int esmk_attn_varlen(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seqlens, const int32_t* qblk_map,
                      int n_qblk, int M, int d, int n_heads, esmk_stream_t stream);
 
+/* Attention of the function-token decoder's stack (reference esm/models/function_decoder.py:92-103,172-174:
+ * TransformerStack(d 1024, 8 heads => head dim 128, qk_layernorm=False) on sequences of exactly 64 tokens with
+ * sequence_id=None, i.e. attention.py:55-78 without mask).  qkv bf16 [n_sequences*64, 3d] straight from the QKV GEMM
+ * (bias included); rotary over the full 128-wide head is applied while staging (rope tables f32 [>=64, 64] computed as
+ * rotary.py:136-177 with dim = 128); ctx bf16 [n_sequences*64, d]. */
+int esmk_attn_l64_d128(const void* qkv_bf16, void* ctx_bf16, const float* rope_cos, const float* rope_sin,
+                       int n_sequences, int d, int n_heads, esmk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Embedding gather: out f32 [M, d] = table[tokens].   Replaces nn.Embedding (esmc.py:63,137).
  * ------------------------------------------------------------------------------------------ */
@@ -262,6 +270,11 @@ typedef struct {
 size_t esmk_head_workspace_bytes(int n_tokens, int d_model);
 int esmk_head_forward(const esmk_head* h, const float* x_norm, float* logits, int M, int d, void* workspace,
                       size_t workspace_bytes, esmk_stream_t stream);
+/* Same head with hidden_dim != d_model (regression_head.py:16; the function decoder's heads: hidden = 4 d,
+ * function_decoder.py:104-125).  w0 packed [hidden, d], b0 / ln_g / ln_b [hidden], w3 packed [out_dim, hidden]. */
+size_t esmk_head_ex_workspace_bytes(int n_tokens, int d_model, int hidden_dim, int out_dim);
+int esmk_head_forward_ex(const esmk_head* h, const float* x, float* logits, int M, int d, int hidden_dim,
+                         void* workspace, size_t workspace_bytes, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Output side: mean over the residues of every segment (LogitsConfig.return_mean_embedding /

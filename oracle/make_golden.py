@@ -399,6 +399,33 @@ def vqenc_cases():
     vqenc_case("vqenc_d1024_vh128", 1024, 128, 2, 4096, 1, 64, wseed=82, cseed=804, nan_frac=0.1)
 
 
+def fdec_case(name, d, H, NL, n_kw, n_ip, B, wseed, tseed, stride=1):
+    """FunctionTokenDecoder.forward (function_decoder.py:127-176): [B, 8] function tokens -> three logit sets."""
+    w = synth.fdec_weights(d, NL, n_kw, n_ip, seed=wseed)
+    m = ref_import.build_fdec(d, H, NL, n_kw, n_ip, w)
+    g = torch.Generator().manual_seed(tseed)
+    tok = torch.randint(4, 260, (B, 8), generator=g)
+    tok[1] = 0          # a <pad> row: every input becomes token 0
+    tok[2, 3] = 2       # one special token inside a row zeroes the whole row too
+    with torch.no_grad():
+        out = m(tok)
+    arrays = dict(kind="fdec", d=d, H=H, NL=NL, n_kw=n_kw, n_ip=n_ip, wseed=wseed, tokens=_np(tok), stride=stride)
+    for k, v in out.items():
+        arrays[k] = _np(v[:, ::stride])
+        arrays["absmax_" + k] = float(v.abs().max())
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        ob = m(tok)
+    for k, v in out.items():
+        arrays["ref_bf16_maxdiff_" + k] = float((ob[k].float() - v).abs().max())
+        print(name, k, "absmax", arrays["absmax_" + k], "reference bf16 (autocast) drift", arrays["ref_bf16_maxdiff_" + k])
+    save(name, **arrays)
+
+
+def fdec_cases():
+    fdec_case("fdec_tiny", 256, 2, 2, 300, 200, 9, wseed=91, tseed=900)
+    fdec_case("fdec_d1024_3l", 1024, 8, 3, 58641, 29026, 6, wseed=92, tseed=901, stride=37)
+
+
 def vqdec_cases():
     # tiny (2 blocks, d 128) incl. a bin-packed sequence_id, and the released geometry (30 blocks, d 1280, 20 heads)
     vqdec_case("vqdec_tiny", 128, 2, 2, 40, [40, 27], wseed=71, tseed=700)
@@ -425,6 +452,8 @@ def main():
         return vqdec_cases()
     if "--vqenc-only" in sys.argv:
         return vqenc_cases()
+    if "--fdec-only" in sys.argv:
+        return fdec_cases()
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -480,6 +509,8 @@ def main():
     vqdec_cases()
     # (viii) VQ-VAE structure encoder, coordinates -> structure tokens
     vqenc_cases()
+    # (ix) function-token decoder forward (block variant bias=True, qk_layernorm=False, GELU FFN, head dim 128)
+    fdec_cases()
 
 
 if __name__ == "__main__":

@@ -116,6 +116,31 @@ def build_vqenc(d_model, v_heads, n_layers, d_out, n_codes, weights: dict):
     return m
 
 
+def build_fdec(d_model, n_heads, n_layers, n_keywords, n_interpro, weights: dict):
+    """The reference FunctionTokenDecoder WITHOUT its constructor: that reads the InterPro entry list and the keyword
+    vocabulary through data_root (a download).  The sub-modules below are exactly the ones the constructor builds
+    (function_decoder.py:85-125); forward() is the reference's own."""
+    install()
+    import torch.nn as nn
+    from esm.layers.regression_head import RegressionHead
+    from esm.layers.transformer_stack import TransformerStack
+    from esm.models.function_decoder import FunctionTokenDecoder, FunctionTokenDecoderConfig
+
+    cfg = FunctionTokenDecoderConfig(d_model=d_model, n_heads=n_heads, n_layers=n_layers, num_interpro_classes=n_interpro,
+                                     keyword_vocabulary_size=n_keywords, interpro_entry_list="", keyword_vocabulary_path="")
+    m = FunctionTokenDecoder.__new__(FunctionTokenDecoder)
+    nn.Module.__init__(m)
+    m.config = cfg
+    m.embedding = nn.Embedding(2 * cfg.function_token_depth * cfg.bits_per_token, d_model)
+    m.decoder = TransformerStack(d_model=d_model, n_heads=n_heads, v_heads=None, n_layers=n_layers, n_layers_geom=0,
+                                 scale_residue=False, bias=True, qk_layernorm=False, ffn_type="gelu", expansion_ratio=4)
+    m.heads = nn.ModuleDict({k: RegressionHead(d_model=d_model, output_dim=o, hidden_dim=4 * d_model)
+                             for k, o in (("keyword_logits", n_keywords), ("keyword_tfidf", n_keywords),
+                                          ("interpro_logits", n_interpro))})
+    m.load_state_dict(weights, strict=True)
+    return m.eval()
+
+
 def build_frames(coords):
     install()
     from esm.utils.structure.affine3d import build_affine3d_from_coordinates

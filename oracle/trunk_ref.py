@@ -73,15 +73,23 @@ def attention_mask(sequence_id):
 # --------------------------------------------------------------------------------------
 # blocks
 # --------------------------------------------------------------------------------------
+def _linear(x, w, name):
+    """nn.Linear with an optional bias (the bias=True block variants, blocks.py:81)."""
+    y = x @ w[name + ".weight"].T
+    return y + w[name + ".bias"] if name + ".bias" in w else y
+
+
 def multi_head_attention(x, sequence_id, w, prefix, n_heads):
-    """esm/layers/attention.py:48-82 (SDPA path).  x [B, L, d]."""
+    """esm/layers/attention.py:48-82 (SDPA path).  x [B, L, d].  Linear biases and the QK-LayerNorm are used when the
+    weight dict has them (bias=True / qk_layernorm=False variants: attention.py:26-36)."""
     B, L, d = x.shape
     dh = d // n_heads
     h = layer_norm(x, w[prefix + "layernorm_qkv.0.weight"], w[prefix + "layernorm_qkv.0.bias"])
-    qkv = h @ w[prefix + "layernorm_qkv.1.weight"].T
+    qkv = _linear(h, w, prefix + "layernorm_qkv.1")
     q, k, v = qkv[..., :d], qkv[..., d : 2 * d], qkv[..., 2 * d :]
-    q = layer_norm(q, w[prefix + "q_ln.weight"])  # full-width, bias-free (:31-33)
-    k = layer_norm(k, w[prefix + "k_ln.weight"])
+    if prefix + "q_ln.weight" in w:  # full-width (:31-33); nn.Identity when qk_layernorm=False
+        q = layer_norm(q, w[prefix + "q_ln.weight"], w.get(prefix + "q_ln.bias"))
+        k = layer_norm(k, w[prefix + "k_ln.weight"], w.get(prefix + "k_ln.bias"))
     cos, sin = rotary_tables(L, dh, dtype=q.dtype)
     q = apply_rotary(q.reshape(B, L, n_heads, dh), cos, sin)
     k = apply_rotary(k.reshape(B, L, n_heads, dh), cos, sin)
@@ -92,13 +100,7 @@ def multi_head_attention(x, sequence_id, w, prefix, n_heads):
         scores = scores.masked_fill(~mask[:, None], float("-inf"))
     p = torch.softmax(scores, dim=-1)
     ctx = torch.einsum("bhij,bjhd->bihd", p, v).reshape(B, L, d)
-    return ctx @ w[prefix + "out_proj.weight"].T
-
-
-def _linear(x, w, name):
-    """nn.Linear with an optional bias (the bias=True block variants, blocks.py:81)."""
-    y = x @ w[name + ".weight"].T
-    return y + w[name + ".bias"] if name + ".bias" in w else y
+    return _linear(ctx, w, prefix + "out_proj")
 
 
 def swiglu_ffn(x, w, prefix):
@@ -108,6 +110,12 @@ def swiglu_ffn(x, w, prefix):
     hid = y.shape[-1] // 2
     y = F.silu(y[..., :hid]) * y[..., hid:]
     return _linear(y, w, prefix + "3")
+
+
+def gelu_ffn(x, w, prefix):
+    """esm/layers/blocks.py:41-48."""
+    h = layer_norm(x, w[prefix + "0.weight"], w[prefix + "0.bias"])
+    return _linear(F.gelu(_linear(h, w, prefix + "1")), w, prefix + "3")
 
 
 def build_frames(coords):

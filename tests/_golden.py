@@ -39,6 +39,8 @@ def weights_for(fx):
         return synth.make_weights(synth.vqdec_shapes(d, int(fx["NL"])), seed=ws)
     if kind == "vqenc":
         return synth.vqenc_weights(d, int(fx["VH"]), int(fx["NL"]), 128, int(fx["n_codes"]), seed=ws)
+    if kind == "fdec":
+        return synth.fdec_weights(d, int(fx["NL"]), int(fx["n_kw"]), int(fx["n_ip"]), seed=ws)
     raise ValueError(kind)
 
 

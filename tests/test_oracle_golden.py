@@ -2,7 +2,7 @@
 import pytest
 import torch
 
-from oracle import trunk_ref, vqvae_ref
+from oracle import function_decoder_ref, trunk_ref, vqvae_ref
 from tests import _golden as G
 
 TOL = 2e-5  # fp32 vs fp32, different op order
@@ -113,3 +113,13 @@ def test_vqvae_structure_encoder(name):
     _close(z, G.t(fx["z"]), 1e-4)
     assert torch.equal(idx, G.t(fx["indices"]))
     _close(zq, G.t(fx["z_q"]), 1e-6)
+
+
+@pytest.mark.parametrize("name", ["fdec_tiny", "fdec_d1024_3l"])
+def test_function_token_decoder(name):
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    out = function_decoder_ref.forward(G.t(fx["tokens"]), w, int(fx["H"]), int(fx["NL"]))
+    st = int(fx["stride"])
+    for k in ("keyword_logits", "keyword_tfidf", "interpro_logits"):
+        _close(out[k][:, ::st], G.t(fx[k]), 1e-4)
