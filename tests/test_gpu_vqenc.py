@@ -200,3 +200,31 @@ def test_encode_decode_roundtrip_shapes_and_determinism():
     tok[:, 0], tok[:, -1] = 4098, 4097
     out = dec.decode(tok)
     assert out["bb_pred"].shape == (3, 302, 3, 3) and torch.isfinite(out["bb_pred"]).all()
+
+
+def test_released_geometry_full_length_against_oracle():
+    """d 1024, 128 vector heads, 4096 codes, one 512-residue protein against the CPU oracle (pinned to the reference by
+    the fixtures above): z within the fixture gate, tokens equal wherever the margin exceeds what dz can move."""
+    from esm_amd import synth
+    from oracle import vqvae_ref
+    fx = G.load("vqenc_d1024_vh128")
+    w = G.weights_for(fx)
+    m = _encoder(fx)
+    coords = synth.synth_backbone(1, 512, seed=123, nan_frac=0.08, jitter=0.15)
+    torch.set_num_threads(16)
+    _, want_idx, want_z = vqvae_ref.encode(coords, w, int(fx["VH"]), int(fx["NL"]))
+    zs = []
+    _, idx = m.encode(coords.cuda(), _z_out=zs)
+    amask = torch.isfinite(coords).all(-1).all(-1)
+    dz = (zs[0].cpu() - want_z)[amask]
+    assert float(dz.abs().max()) <= 0.02 * float(want_z.abs().max()) + 0.02, float(dz.abs().max())
+    codes = w["codebook.embeddings"]
+    flat = want_z[amask]
+    dist = (flat ** 2).sum(1, keepdim=True) - 2 * flat @ codes.T + (codes.T ** 2).sum(0, keepdim=True)
+    top2 = dist.topk(2, dim=1, largest=False)
+    gap = (codes[top2.indices[:, 0]] - codes[top2.indices[:, 1]]).norm(dim=-1)
+    safe = (top2.values[:, 1] - top2.values[:, 0]) > 2 * dz.norm(dim=-1) * gap
+    got, want = idx.cpu()[amask], want_idx[amask]
+    assert torch.equal(got[safe], want[safe])
+    assert float((got == want).float().mean()) >= 0.9 and float(safe.float().mean()) >= 0.5
+    assert torch.equal(idx.cpu()[~amask], want_idx[~amask])

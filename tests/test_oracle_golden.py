@@ -82,14 +82,16 @@ def test_esm3(name):
 VQDEC_KEYS = ("tensor7_affine", "bb_pred", "plddt", "ptm", "predicted_aligned_error")
 
 
-@pytest.mark.parametrize("name", ["vqdec_tiny", "vqdec_tiny_seqid", "vqdec_d1280_30l"])
+@pytest.mark.parametrize("name", ["vqdec_tiny", "vqdec_tiny_seqid", "vqdec_d1280_30l", "vqdec_d1280_30l_L512"])
 def test_vqvae_structure_decoder(name):
     fx = G.load(name)
     w = G.weights_for(fx)
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
     out = vqvae_ref.decode(G.t(fx["tokens"]), w, int(fx["H"]), int(fx["NL"]), sequence_id=sid)
+    st = int(fx["pae_stride"]) if "pae_stride" in fx else 1
+    out["predicted_aligned_error"] = out["predicted_aligned_error"][:, ::st, ::st]
     for k in VQDEC_KEYS:
-        _close(out[k], G.t(fx[k]), 1e-4 if name == "vqdec_d1280_30l" else TOL)
+        _close(out[k], G.t(fx[k]), 1e-4 if name.startswith("vqdec_d1280") else TOL)
 
 
 VQENC = ["vqenc_tiny", "vqenc_tiny_seqid_resindex", "vqenc_tiny_short", "vqenc_tiny_sparse", "vqenc_d1024_vh128"]
