@@ -20,6 +20,7 @@ class ESMProtein:
     coordinates: torch.Tensor | None = None
     plddt: torch.Tensor | None = None
     ptm: torch.Tensor | None = None
+    pae: torch.Tensor | None = None
     potential_sequence_of_concern: bool = False
 
     def __len__(self) -> int:

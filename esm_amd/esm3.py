@@ -1,6 +1,7 @@
 """ESM3 forward / logits with the reference's Python surface (reference esm/models/esm3.py:50-178,
 260-374,503-559) on the HIP trunk: 8-track input encoder, backbone frames, 48-block stack whose first
-block has geometric attention, six regression heads.  generate/encode/decode are out of scope.
+block has geometric attention, six regression heads; `encode` / `decode` for the sequence and structure tracks over
+the VQ-VAE models of esm_amd/vqvae.py (esm3.py:414-501, utils/encoding.py:48-97, utils/decoding.py:28-169).
 """
 from __future__ import annotations
 
@@ -12,7 +13,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .affine3d import build_affine3d_from_coordinates
-from .api import ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
+from .api import ESMProtein, ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
 from .engine import HeadEngine, _f32, _stream
 from .esmc import RegressionHeadParams
 from .transformer_stack import TransformerStack
@@ -69,6 +70,10 @@ class ESM3(nn.Module):
         self.output_heads = OutputHeads(d_model)
         self.tokenizers = tokenizers or SimpleNamespace(sequence=SimpleNamespace(mask_token_id=SEQUENCE_MASK_TOKEN))
         self.d_model = d_model
+        # builders `fn(device) -> model`, as in the reference (esm3.py:181-258); built lazily
+        self.structure_encoder_fn, self.structure_decoder_fn = structure_encoder_fn, structure_decoder_fn
+        self.function_decoder_fn = function_decoder_fn
+        self._structure_encoder = self._structure_decoder = self._function_decoder = None
         self._enc = None
         self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
 
@@ -274,6 +279,83 @@ class ESM3(nn.Module):
             setattr(q, track, done[i, :lens[i]].clone())
             outs.append(q)
         return outs
+
+    # ---- structure / function models (esm3.py:245-258) ---------------------------------------------
+    def _built(self, slot, fn, what):
+        if getattr(self, slot) is None:
+            if fn is None:
+                raise ValueError(f"this ESM3 was constructed without a {what} builder ({what}_fn)")
+            setattr(self, slot, fn(self.device))
+        return getattr(self, slot)
+
+    def get_structure_encoder(self):
+        return self._built("_structure_encoder", self.structure_encoder_fn, "structure_encoder")
+
+    def get_structure_decoder(self):
+        return self._built("_structure_decoder", self.structure_decoder_fn, "structure_decoder")
+
+    def get_function_decoder(self):
+        return self._built("_function_decoder", self.function_decoder_fn, "function_decoder")
+
+    # ---- ESMProtein <-> ESMProteinTensor for the sequence and structure tracks ----------------------
+    @torch.no_grad()
+    def encode(self, input: ESMProtein) -> ESMProteinTensor:
+        """esm3.py:414-493 for `sequence` and `coordinates` (secondary structure, SASA and function annotations need
+        the reference's other tokenizers and their data files: NotImplementedError).  coordinates [L, >=3, 3] with
+        N, CA, C first (atom37 works), NaN where unknown -> structure tokens from the VQ-VAE encoder, BOS / EOS added,
+        coordinates padded with inf rows (utils/encoding.py:48-97)."""
+        from .tokenization import EsmSequenceTokenizer, tokenize_sequence
+        if input.secondary_structure is not None or input.sasa is not None:
+            raise NotImplementedError("only the sequence and structure tracks can be encoded here")
+        dev = self.device
+        seq_tok = struct_tok = coords = None
+        if input.sequence is not None:
+            tok = getattr(self.tokenizers, "sequence", None)
+            if not hasattr(tok, "encode"):
+                tok = EsmSequenceTokenizer()
+            seq_tok = tokenize_sequence(input.sequence, tok, add_special_tokens=True).to(dev)
+        if input.coordinates is not None:
+            c = input.coordinates.to(dev, torch.float32)
+            if input.sequence and len(input.sequence) != c.size(0):
+                raise ValueError(f"Reference sequence length ({len(input.sequence)}) does not match the number of residues "
+                                 f"in the coordinates ({c.size(0)})")
+            res = torch.arange(c.size(0), device=dev)[None]
+            _, t = self.get_structure_encoder().encode(c[None], residue_index=res)
+            struct_tok = torch.nn.functional.pad(t[0], (1, 1), value=STRUCTURE_MASK_TOKEN)
+            struct_tok[0], struct_tok[-1] = STRUCTURE_BOS_TOKEN, STRUCTURE_EOS_TOKEN
+            coords = torch.nn.functional.pad(c, (0, 0, 0, 0, 1, 1), value=torch.inf)
+        if seq_tok is None and struct_tok is None:
+            raise ValueError("Cannot infer input length from input data. Please provide one of: sequence, structure")
+        return ESMProteinTensor(sequence=seq_tok, structure=struct_tok, coordinates=coords,
+                                potential_sequence_of_concern=input.potential_sequence_of_concern)
+
+    @torch.no_grad()
+    def decode(self, input: ESMProteinTensor) -> ESMProtein:
+        """utils/decoding.py:28-111 for the sequence and structure tracks: the structure tokens (when none of them is
+        MASK) go through the VQ-VAE decoder and take priority over `coordinates`.  coordinates come back as the
+        backbone N, CA, C [L, 3, 3]: all-atom reconstruction (`ProteinChain.infer_oxygen`) is out of scope."""
+        from .tokenization import EsmSequenceTokenizer, decode_sequence
+        from .vqvae import decode_structure
+        if input.secondary_structure is not None or input.sasa is not None or input.function is not None or \
+                input.residue_annotations is not None:
+            raise NotImplementedError("only the sequence and structure tracks can be decoded here")
+        sequence = coords = plddt = ptm = pae = None
+        if input.sequence is not None and not bool((input.sequence[1:-1] == SEQUENCE_PAD_TOKEN).all()):
+            tok = getattr(self.tokenizers, "sequence", None)
+            if not hasattr(tok, "decode"):
+                tok = EsmSequenceTokenizer()
+            sequence = decode_sequence(input.sequence, tok)
+        st = input.structure
+        if st is not None:
+            body = st[1:-1]
+            if bool((body == STRUCTURE_PAD_TOKEN).all()) or bool((body == STRUCTURE_MASK_TOKEN).any()):
+                st = None
+        if st is not None:
+            coords, plddt, ptm, pae = decode_structure(st.to(self.device), self.get_structure_decoder())
+        elif input.coordinates is not None:
+            coords = input.coordinates[1:-1, ...]
+        return ESMProtein(sequence=sequence, coordinates=coords, plddt=plddt, ptm=ptm, pae=pae,
+                          potential_sequence_of_concern=input.potential_sequence_of_concern)
 
     def forward_and_sample(self, input: ESMProteinTensor, sampling_configuration, generator=None):
         """One forward + one sampling step per configured track (reference esm3.py:561-599 with
