@@ -78,9 +78,11 @@ def test_knn_edges_match_reference(name):
     G.assert_knn_equal(edges.cpu(), emask.cpu(), fx)
 
 
-def test_geom_attn_neighbourhood_rows():
-    """esmk_geom_attn_ex with mask_and_zero_frameless = 0 on rows of <= 16 tokens against the oracle, incl. rows whose
-    keys are all masked (uniform attention) and frameless queries (not zeroed)."""
+@pytest.mark.parametrize("zf", [0, 1])
+def test_geom_attn_neighbourhood_rows(zf):
+    """esmk_geom_attn_ex on rows of <= 16 tokens (fused kernel) against the oracle, with mask_and_zero_frameless = 0
+    (rows whose keys are all masked get uniform attention, frameless queries are not zeroed) and = 1 (ESM3's setting:
+    frameless queries give zeros)."""
     from oracle import trunk_ref
     L, lib, s = _lib()
     g = torch.Generator().manual_seed(3)
@@ -102,7 +104,7 @@ def test_geom_attn_neighbourhood_rows():
     wd["proj.weight"] = torch.eye(15 * H)
     wd["out_proj.weight"] = torch.eye(3 * H)
     x = proj
-    want = trunk_ref.geometric_attention(x, rot, trans, amask, seq, chain, wd, "", H, mask_and_zero_frameless=False)
+    want = trunk_ref.geometric_attention(x, rot, trans, amask, seq, chain, wd, "", H, mask_and_zero_frameless=bool(zf))
     aff = torch.cat([rot.flatten(-2), trans], dim=-1).reshape(M, 12).contiguous().cuda()
     pd = trunk_ref.layer_norm(x, wd["s_norm.weight"]).reshape(M, 15 * H).contiguous().cuda()
     out = torch.empty(M, 64, dtype=torch.bfloat16, device="cuda")
@@ -112,10 +114,13 @@ def test_geom_attn_neighbourhood_rows():
     am, sq, ch = dev(amask, torch.uint8), dev(seq, torch.int32), dev(chain, torch.int32)
     ds, rs = w["distance_scale_per_head"].cuda(), w["rotation_scale_per_head"].cuda()
     L.check(lib.esmk_geom_attn_ex(L.ptr(pd), L.ptr(aff), L.ptr(am), L.ptr(sq), L.ptr(ch), L.ptr(row_cu), R, E, L.ptr(ds),
-                                  L.ptr(rs), L.ptr(out), 64, L.ptr(scratch), M, H, 0, s))
+                                  L.ptr(rs), L.ptr(out), 64, L.ptr(scratch), M, H, zf, s))
     got = out.float().cpu()[:, :3 * H].reshape(R, E, 3 * H)
     np.testing.assert_allclose(got.numpy(), want.numpy(), atol=2e-2 * float(want.abs().max()), rtol=0)
-    assert float(want[5].abs().max()) > 0  # the all-masked neighbourhood really exercises the uniform branch
+    if zf == 0:
+        assert float(want[5].abs().max()) > 0  # the all-masked neighbourhood really exercises the uniform branch
+    else:
+        assert float(got[~amask].abs().max()) == 0.0
     assert float(out[:, 3 * H:].abs().max()) == 0.0
 
 
