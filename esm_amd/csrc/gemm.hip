@@ -269,6 +269,7 @@ int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, co
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                  float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
+int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s);
 
@@ -336,9 +337,21 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
         static int use288 = -1;
         if (use288 < 0) { const char* e5 = getenv("ESMK_GEMM_288"); use288 = e5 ? atoi(e5) : 1; }
+        static int force192 = -1;  // ESMK_GEMM_192=1: prefer 192-channel tiles wherever N % 192 == 0 (experiments)
+        if (force192 < 0) { const char* e6 = getenv("ESMK_GEMM_192"); force192 = e6 ? atoi(e6) : 0; }
+        if (force192 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 192) == 0 && (long long)((M + 255) / 256) * (N / 192) >= 128)
+            return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
         if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
             (long long)((M + 255) / 256) * (N / 288) >= 128)
             return esmk_gemm288(A, lda, W, M, N, K, alpha, out, s);
+        // 192-channel tiles when they need fewer tile-width-weighted rounds of workgroups than 256-wide ones
+        // (d_model 1536 at 8192 tokens: N = 1536 is 256 workgroups of 192 channels = one full round, but 192
+        // workgroups of 256 = one round at 75 %; N = 4608: 3 rounds either way, of narrower tiles)
+        if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 192) == 0) {
+            const long long nt = (M + 255) / 256;
+            const long long c192 = (nt * (N / 192) + 255) / 256 * 192, c256 = (nt * ((N + 255) / 256) + 255) / 256 * 256;
+            if (nt * (N / 192) >= 128 && c192 < c256) return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
+        }
         if ((ov == 256 && !bias128) || (ov == 0 && big)) {
             // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
             // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call

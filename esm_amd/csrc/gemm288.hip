@@ -19,12 +19,20 @@
 
 namespace {
 
-constexpr int TC = 288, TT = 256, BK = 64;
+// NQM = channel row groups of 48 per wave: 3 -> 288-channel tiles, 2 -> 192-channel tiles (d_model 1536 at 8192
+// tokens: 1536 = 8 x 192 gives exactly 256 workgroups per round where 256-wide tiles give 192)
+constexpr int TT = 256, BK = 64;
 constexpr int UB = 128 * 128, UA = 96 * 128;
 constexpr int OFF_UB0 = 0, OFF_UB1 = UB, OFF_UA0 = 2 * UB, OFF_UA1 = 2 * UB + UA, OFF_UA2 = 2 * UB + 2 * UA;
-constexpr int KBUF = 2 * UB + 3 * UA;                 // 69632 B
-constexpr int PITCH = 144 * 2 + 16;                   // epilogue staging row pitch
-constexpr int LDS_BYTES = 8 * 64 * PITCH;             // 155648 B >= 2 * KBUF
+template <int NQM> struct Cfg {
+    static constexpr int TC = 96 * NQM;                    // channels per tile
+    static constexpr int WC = 48 * NQM;                    // channels per wave
+    static constexpr int KBUF = 2 * UB + NQM * UA;         // 69632 B (288) / 57344 B (192)
+    static constexpr int PITCH = WC * 2 + 16;              // epilogue staging row pitch
+    static constexpr int LDS_BYTES = (8 * 64 * PITCH > 2 * KBUF) ? 8 * 64 * PITCH : 2 * KBUF;
+    static constexpr int LPR = WC / 8;                     // lanes per staged row (16 B each): 18 / 12
+    static constexpr int RPI = 64 / LPR;                   // rows per wave instruction: 3 / 5
+};
 
 #define SEG_BARRIER()                        \
     do {                                     \
@@ -33,11 +41,14 @@ constexpr int LDS_BYTES = 8 * 64 * PITCH;             // 155648 B >= 2 * KBUF
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
-template <bool HI>  // HI: waves 0-3 (six P pieces per K-tile), else five
+template <int NQM, bool HI>  // HI: waves 0-3 (six P pieces per K-tile), else five
 __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ W, int ldw,
                                              int M, int N, int ktiles, float alpha, __bf16* __restrict__ out, int c0,
                                              int t0, char* smem) {
-    constexpr int NP = HI ? 6 : 5, NQ = 3;
+    using C = Cfg<NQM>;
+    constexpr int KBUF = C::KBUF, PITCH = C::PITCH;
+    // Q region = UA1 (.. UA2): 12 (NQM - 1) pieces over 8 waves -> 3 per wave (288) / 2 for waves 0-3 and 1 else (192)
+    constexpr int NP = HI ? 6 : 5, NQ = (NQM == 3) ? 3 : (HI ? 2 : 1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -49,7 +60,7 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     const char* abase = (const char*)(A + (size_t)t0 * lda);
     auto a_row_off = [&](int unit_row, int qm) {  // channel row of UA[qm] -> byte offset from wbase
         const int w2 = unit_row / 48, rem = unit_row - w2 * 48;
-        return (unsigned)(w2 * 144 + qm * 48 + rem) * (unsigned)(ldw * 2);
+        return (unsigned)(w2 * C::WC + qm * 48 + rem) * (unsigned)(ldw * 2);
     };
     auto b_row_off = [&](int unit_row, int qn) {  // token row of UB[qn] -> byte offset from abase (clamped to M-1)
         int tr = (unit_row >> 5) * 64 + qn * 32 + (unit_row & 31);
@@ -71,7 +82,8 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int p = wave + 8 * j;                       // 0..23: UA1 = 0..11, UA2 = 12..23
+        int p = wave + 8 * j;                             // 0..23: UA1 = 0..11, UA2 = 12..23
+        if (p >= 12 * (NQM - 1)) p = 12 * (NQM - 1) - 1;  // pieces this wave never issues (j >= NQ)
         const int qm = p < 12 ? 1 : 2;
         const int ur = (p - (qm - 1) * 12) * 8 + (lane >> 3);
         soffQ[j] = a_row_off(ur, qm) + (((lane & 7) ^ ((ur >> 1) & 7)) << 4);
@@ -100,9 +112,9 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     const int a_off = ra * 128 + (((lane >> 4) ^ ((ra >> 1) & 7)) << 4);
     const int b_off = rb * 128 + (((lane >> 4) ^ ((rb >> 1) & 7)) << 4);
 
-    f32x4 acc[3][2][3][2];  // [qm][qn][mi][ni]
+    f32x4 acc[NQM][2][3][2];  // [qm][qn][mi][ni]
 #pragma unroll
-    for (int a = 0; a < 3; ++a)
+    for (int a = 0; a < NQM; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -172,15 +184,17 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
                    { if (M2) issue_P(1, kt + 2); }, { if (M2) issue_P(2, kt + 2); },               \
                    { if (M2) issue_P(3, kt + 2); }, { if (M2) issue_P(4, kt + 2); })               \
         MFMA_BLOCK(1, 0, { read_a_kk(cur + OFF_UA1, 1); }, { if (M2 && HI) issue_P(5, kt + 2); }, NOP_, NOP_, NOP_, NOP_) \
-        MFMA_BLOCK(1, 1, { read_a_kk(cur + OFF_UA2, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
-        MFMA_BLOCK(2, 0, { read_a_kk(cur + OFF_UA2, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        if constexpr (NQM == 3) {                                                                  \
+            MFMA_BLOCK(1, 1, { read_a_kk(cur + OFF_UA2, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_)       \
+            MFMA_BLOCK(2, 0, { read_a_kk(cur + OFF_UA2, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)       \
+        }                                                                                          \
         if (M2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NQ) : "memory");                     \
         else if (M1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");                     \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
         SEG_BARRIER();                                                                             \
-        MFMA_BLOCK(2, 1, { if (M1) { read_a_kk(nxt + OFF_UA0, 0); read_b_kk(nxt, 0); } },          \
-                   { if (M2) issue_Q(0, kt + 2); }, { if (M2) issue_Q(1, kt + 2); },               \
-                   { if (M2) issue_Q(2, kt + 2); }, NOP_, NOP_)                                    \
+        MFMA_BLOCK(NQM - 1, 1, { if (M1) { read_a_kk(nxt + OFF_UA0, 0); read_b_kk(nxt, 0); } },    \
+                   { if (M2 && NQ > 0) issue_Q(0, kt + 2); }, { if (M2 && NQ > 1) issue_Q(1, kt + 2); }, \
+                   { if (M2 && NQ > 2) issue_Q(2, kt + 2); }, NOP_, NOP_)                          \
     }
 
     int kt = 0;
@@ -201,7 +215,7 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     const int q4 = (lane >> 4) * 4;
     char* stg = smem + wave * (64 * PITCH);
 #pragma unroll
-    for (int qm = 0; qm < 3; ++qm)
+    for (int qm = 0; qm < NQM; ++qm)
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -217,20 +231,22 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
                 }
             }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    // 18 lanes cover one 288-byte row: 3 rows per wave instruction (lanes 0..53)
-    const int lr = lane / 18, lc = lane - lr * 18;
-    const int cc = c0 + wm * 144 + lc * 8;
+    // LPR lanes cover one row of WC channels (288 / 192 bytes): RPI rows per wave instruction
+    constexpr int LPR = C::LPR, RPI = C::RPI;
+    const int lr = lane / LPR, lc = lane - lr * LPR;
+    const int cc = c0 + wm * C::WC + lc * 8;
 #pragma unroll
-    for (int it = 0; it < 22; ++it) {
-        const int trow = it * 3 + lr;
+    for (int it = 0; it < (64 + RPI - 1) / RPI; ++it) {
+        const int trow = it * RPI + lr;
         const int t = t0 + wn * 64 + trow;
-        if (lane < 54 && trow < 64 && t < M) {
+        if (lane < LPR * RPI && trow < 64 && t < M) {
             const u32x4 v = *(const u32x4*)(stg + trow * PITCH + lc * 16);
             *(u32x4*)(out + (size_t)t * N + cc) = v;
         }
     }
 }
 
+template <int NQM>
 __global__ __launch_bounds__(512, 2) void gemm288_kernel(const __bf16* __restrict__ A, int lda,
                                                          const __bf16* __restrict__ W, int ldw, int M, int N,
                                                          int ktiles, float alpha, __bf16* __restrict__ out,
@@ -243,31 +259,41 @@ __global__ __launch_bounds__(512, 2) void gemm288_kernel(const __bf16* __restric
     const int gtp = min(gt, n_ttile - panel * gt);
     const int idp = id - panel * gt * n_ctile;
     const int ctile = idp / gtp, ttile = panel * gt + (idp - ctile * gtp);
-    const int c0 = ctile * TC, t0 = ttile * TT;
+    const int c0 = ctile * Cfg<NQM>::TC, t0 = ttile * TT;
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4)
-        gemm288_body<true>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+        gemm288_body<NQM, true>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
     else
-        gemm288_body<false>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+        gemm288_body<NQM, false>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
 }
 
-}  // namespace
-
-// Called by esmk_gemm (gemm.hip): N % 288 == 0, bf16 output.  W packed with rows padded to 256 (>= N rows exist).
-int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+template <int NQM>
+static int launch288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+    using C = Cfg<NQM>;
     const int Kpad = round_up(K, BK);
-    const int n_ctile = N / TC;
+    const int n_ctile = N / C::TC;
     const int n_ttile = (M + TT - 1) / TT;
     const int nblk = n_ctile * n_ttile;
     static int gt = 0;
     if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm288_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", LDS_BYTES);
+        if (hipFuncSetAttribute((const void*)gemm288_kernel<NQM>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
+            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", C::LDS_BYTES);
         attr_done = true;
     }
-    hipLaunchKernelGGL(gemm288_kernel, dim3(nblk), dim3(512), LDS_BYTES, s, (const __bf16*)A, lda, (const __bf16*)W, Kpad,
-                       M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt);
-    ESMK_CHECK_LAUNCH("esmk_gemm(288)");
+    hipLaunchKernelGGL(gemm288_kernel<NQM>, dim3(nblk), dim3(512), C::LDS_BYTES, s, (const __bf16*)A, lda, (const __bf16*)W,
+                       Kpad, M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt);
+    ESMK_CHECK_LAUNCH("esmk_gemm(288/192)");
     return ESMK_OK;
+}
+
+}  // namespace
+
+// Called by esmk_gemm (gemm.hip): N % 288 == 0 (or N % 192 == 0 for esmk_gemm192), bf16 output.  W packed with rows
+// padded to 256 (>= N rows exist).
+int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+    return launch288<3>(A, lda, W, M, N, K, alpha, out, s);
+}
+int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+    return launch288<2>(A, lda, W, M, N, K, alpha, out, s);
 }

@@ -272,6 +272,26 @@ def test_gemm_288_channel_tiles(M, N, K):
     assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
 
 
+@pytest.mark.parametrize("M,N,K", [(8192, 1536, 64), (8192, 1536, 128), (8192, 1536, 192), (8192, 1536, 4096),
+                                   (8192, 4608, 1536), (8100, 1536, 1536), (16384, 1536, 1536)])
+def test_gemm_192_channel_tiles(M, N, K):
+    """d_model 1536 at 8 k / 16 k tokens takes the 192x256 kernel (full rounds of workgroups where 256-wide tiles leave
+    a quarter of the CUs idle); 1, 2, 3, 64, 24 K-tiles; ragged M."""
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = torch.randn(N, K, generator=g) * 0.05
+    Wp = engine.pack_weight(W, "cuda")
+    ref = 0.5 * (A.float() @ W.bfloat16().float().cuda().T)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    for _ in range(2):
+        L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_BF16, None, 0.5, out.data_ptr(), _s()))
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    err = (out.float() - ref).abs().max().item()
+    assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
+
+
 def test_add2_layernorm_modes():
     """Two-delta LayerNorm: no-write mode leaves x alone; the two-delta write mode equals two single adds bit for bit."""
     L, lib, engine = _env()

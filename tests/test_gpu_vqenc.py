@@ -78,15 +78,15 @@ def test_knn_edges_match_reference(name):
     G.assert_knn_equal(edges.cpu(), emask.cpu(), fx)
 
 
-@pytest.mark.parametrize("zf", [0, 1])
-def test_geom_attn_neighbourhood_rows(zf):
+@pytest.mark.parametrize("E,zf", [(16, 0), (16, 1), (11, 0), (40, 0)])
+def test_geom_attn_neighbourhood_rows(E, zf):
     """esmk_geom_attn_ex on rows of <= 16 tokens (fused kernel) against the oracle, with mask_and_zero_frameless = 0
     (rows whose keys are all masked get uniform attention, frameless queries are not zeroed) and = 1 (ESM3's setting:
     frameless queries give zeros)."""
     from oracle import trunk_ref
     L, lib, s = _lib()
     g = torch.Generator().manual_seed(3)
-    R, E, H = 37, 16, 8
+    R, H = 37, 8  # E <= 16: fused small-row kernel; E = 40: the general kernel with the flag off
     M = R * E
     proj = torch.randn(R, E, 15 * H, generator=g)
     coords = torch.randn(R, E, 3, 3, generator=g) * 3
