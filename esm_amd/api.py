@@ -89,6 +89,13 @@ class _BatchedESMProteinTensor(ESMProteinTensor):
 
 
 @dataclass
+class ESMProteinError(Exception):
+    """esm/sdk/api.py:285-288: what batch_generate returns in place of a prompt that could not be decoded."""
+    error_code: int  # HTTP convention: 500 = internal error
+    error_msg: str
+
+
+@dataclass
 class ForwardTrackData:
     sequence: torch.Tensor | None = None
     structure: torch.Tensor | None = None

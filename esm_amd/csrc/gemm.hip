@@ -268,10 +268,21 @@ int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, co
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                  float alpha, void* out, hipStream_t s, int n_ctile);
+int esmk_gemm4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s);
+
+// ESMK_GEMM_4W=1: the four-wave 128x128-wave-tile kernel (gemm4w.hip) takes the place of the eight-wave 256-tile
+// kernel (A/B experiments; read per call so that tests can exercise both)
+static int gemm256_or_4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                         float alpha, void* out, hipStream_t s, int n_ctile) {
+    const char* e = getenv("ESMK_GEMM_4W");
+    if (e && atoi(e)) return esmk_gemm4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
+    return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
+}
 
 // 0 = auto, 128 / 256 = force a tile family (ESMK_GEMM_TILE environment variable; for experiments and tests)
 static int gemm_tile_override() {
@@ -372,8 +383,8 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
             if (split_on < 0) { const char* e2 = getenv("ESMK_GEMM_SPLIT"); split_on = e2 ? atoi(e2) : 1; }
             const bool split = split_on && !persist && nc >= 2 && rem <= 128 && epilogue != ESMK_EPI_SWIGLU &&
                                (nt * (nc - 1) + 255) / 256 < (nt * nc + 255) / 256;
-            if (!split) return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc);
-            const int rc = esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc - 1);
+            if (!split) return gemm256_or_4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc);
+            const int rc = gemm256_or_4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc - 1);
             if (rc != ESMK_OK) return rc;
             const int ct0 = (nc - 1) * 2;
             switch (epilogue) {

@@ -241,6 +241,10 @@ class ESM3(nn.Module):
 
         def stack(name):
             rows = [getattr(p, name) for p in prompts]
+            if name == "structure" and config.condition_on_coordinates_only:
+                # generation.py:367-370: a prompt with coordinates is conditioned on them alone - its structure tokens
+                # are dropped (and decoded from scratch when structure is the target track)
+                rows = [None if p.coordinates is not None else r for p, r in zip(prompts, rows)]
             if all(r is None for r in rows) and name != track:
                 return None
             bos, eos, pad, mask = self._TRACK_IDS[name]
@@ -260,8 +264,6 @@ class ESM3(nn.Module):
             for i, p in enumerate(prompts):
                 if p.coordinates is not None:
                     coords[i, :lens[i]] = p.coordinates[..., :3, :].to(dev)
-        if config.condition_on_coordinates_only and coords is not None and track != "structure":
-            tracks["structure"] = None  # generation.py:367-370
         cfg_field = {"sequence": "sequence", "structure": "structure", "secondary_structure": "secondary_structure", "sasa": "sasa"}[track]
 
         def logits_fn(cur):
@@ -279,6 +281,78 @@ class ESM3(nn.Module):
             setattr(q, track, done[i, :lens[i]].clone())
             outs.append(q)
         return outs
+
+    def generate(self, input, config):
+        """esm3.py:377-381: one prompt through batch_generate."""
+        proteins = self.batch_generate([input], [config])
+        assert len(proteins) == 1
+        return proteins[0]
+
+    def batch_generate(self, inputs: list, configs: list, generator=None) -> list:
+        """esm3.py:383-412 with iterative_sampling_raw / iterative_sampling_tokens (utils/generation.py:99-127,
+        355-534).  ESMProtein prompts are encoded, decoded as tokens and turned back into ESMProtein;
+        ESMProteinTensor prompts come back as ESMProteinTensor.  Every prompt has its own GenerationConfig: like the
+        reference, a prompt with fewer masked positions than `num_steps` gets its `config.num_steps` lowered to that
+        number (in place).  Prompts whose configs then agree share one batched decoding loop (one forward and one
+        sampling kernel per step for the whole group; the reference loops over prompts in Python at every step).
+        A prompt that cannot be decoded - `coordinates` / `residue_annotations` track, no masked position - yields an
+        ESMProteinError(500) in its slot and does not disturb the others (generation.py:423-431,493-495)."""
+        import dataclasses
+
+        from .api import ESMProteinError
+        assert len(inputs) == len(configs), "Must have the same number of prompts and configs."
+        if inputs == []:
+            return []
+        t = type(inputs[0])
+        for x in inputs[1:]:
+            assert isinstance(x, t), f"Prompts must have the same type. Got {t.__name__} and {type(x).__name__} instead."
+        if isinstance(inputs[0], ESMProtein):
+            toks = [self.encode(p) for p in inputs]
+            outs = self.batch_generate(toks, configs, generator=generator)
+            return [o if isinstance(o, ESMProteinError) else self.decode(o) for o in outs]
+        if not isinstance(inputs[0], ESMProteinTensor):
+            raise ValueError("Input must be an ESMProtein or ESMProteinTensor")
+        devices = {p.device for p in inputs}
+        if len(devices) > 1:
+            raise AttributeError(f"Input tokens on multiple devices {devices}")
+        from .sampling import default_track_tokenizers
+        toks = default_track_tokenizers()
+        results: list = [None] * len(inputs)
+        groups: dict = {}
+        for i, (p, cfg) in enumerate(zip(inputs, configs)):
+            track = cfg.track
+            if track in ("coordinates", "residue_annotations"):
+                results[i] = ESMProteinError(500, f"Iterative sampling {track} is not supported.")
+                continue
+            if track not in self._TRACK_IDS:
+                results[i] = ESMProteinError(500, f"track {track!r} cannot be generated here (needs tokenizer data files)")
+                continue
+            cur = getattr(p, track)
+            if track == "structure" and cfg.condition_on_coordinates_only and p.coordinates is not None:
+                cur = None
+            if cur is None:  # the whole track is decoded: every non-special sequence position (generation.py:333-347)
+                if p.sequence is None:
+                    n_masks = len(p) - 2
+                else:
+                    special = [x for x in toks["sequence"].special_token_ids if x != SEQUENCE_MASK_TOKEN]
+                    n_masks = int((~torch.isin(p.sequence.cpu(), torch.tensor(special))).sum())
+            else:
+                m = cur == toks[track].mask_token_id
+                m[0], m[-1] = False, False
+                n_masks = int(m.sum())
+            if n_masks == 0:
+                results[i] = ESMProteinError(500, f"Cannot sample {track} when input has no masks.")
+                continue
+            if n_masks < cfg.num_steps:
+                cfg.num_steps = n_masks
+            key = tuple((f.name, tuple(v) if isinstance(v, (list, tuple)) else v)
+                        for f in dataclasses.fields(cfg) for v in [getattr(cfg, f.name)])
+            groups.setdefault(key, []).append(i)
+        for idx in groups.values():
+            done = self.generate_tokens([inputs[i] for i in idx], configs[idx[0]], generator=generator)
+            for i, d in zip(idx, done):
+                results[i] = d
+        return results
 
     # ---- structure / function models (esm3.py:245-258) ---------------------------------------------
     def _built(self, slot, fn, what):

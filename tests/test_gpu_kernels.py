@@ -42,11 +42,13 @@ def test_gemm_bf16_and_f32(M, N, K):
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(8192, 2304, 256, False), (8000, 2560, 192, False), (8192, 4608, 128, True),
                                             (5000, 6144, 1152, True), (70000, 1152, 320, False)])
-@pytest.mark.parametrize("persist", ["0", "1"])
-def test_gemm_many_tiles(M, N, K, swiglu, persist, monkeypatch):
-    """More 256x256 tiles than CUs, ragged M, a ragged channel tile, 2..18 K-tiles - on the default kernel and on
-    the persistent one (several tiles per workgroup, cross-tile prefetch, store-aware vmcnt)."""
+@pytest.mark.parametrize("persist,fourw", [("0", "0"), ("1", "0"), ("0", "1")])
+def test_gemm_many_tiles(M, N, K, swiglu, persist, fourw, monkeypatch):
+    """More 256x256 tiles than CUs, ragged M, a ragged channel tile, 2..18 K-tiles - on the default kernel, on
+    the persistent one (several tiles per workgroup, cross-tile prefetch, store-aware vmcnt) and on the four-wave
+    128x128-wave-tile kernel (gemm4w.hip)."""
     monkeypatch.setenv("ESMK_GEMM_PERSIST", persist)
+    monkeypatch.setenv("ESMK_GEMM_4W", fourw)
     L, lib, engine = _env()
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
@@ -65,6 +67,32 @@ def test_gemm_many_tiles(M, N, K, swiglu, persist, monkeypatch):
     assert torch.isfinite(out.float()).all()
     err = (out.float() - ref).abs().max().item()
     assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
+
+
+@pytest.mark.parametrize("fourw", ["0", "1"])
+@pytest.mark.parametrize("M,N,K", [(8192, 1024, 64), (9000, 1100, 192)])
+def test_gemm_256_tile_other_epilogues(M, N, K, fourw, monkeypatch):
+    """fp32 (+bias), residual and bias+GELU epilogues of the two 256-tile kernels on problems big enough to reach
+    them (>= 128 tiles), ragged M and a ragged channel column included; one K-tile and three."""
+    monkeypatch.setenv("ESMK_GEMM_4W", fourw)
+    L, lib, engine = _env()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).bfloat16().cuda()
+    W = torch.randn(N, K, generator=g) * 0.1
+    Wp = engine.pack_weight(W, "cuda")
+    b = torch.randn(N, generator=g).cuda()
+    y = A.float() @ W.bfloat16().float().cuda().T
+    o32 = torch.full((M, N), float("nan"), device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_F32, b.data_ptr(), 1.0, o32.data_ptr(), _s()))
+    assert (o32 - (y + b)).abs().max().item() <= 2e-3 * max(1.0, y.abs().max().item())
+    x0 = torch.randn(M, N, generator=g).cuda()
+    x = x0.clone()
+    L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_RESIDUAL, None, 0.75, x.data_ptr(), _s()))
+    assert (x - (x0 + 0.75 * y)).abs().max().item() <= 2e-3 * max(1.0, y.abs().max().item())
+    o = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_gemm(A.data_ptr(), K, Wp.data_ptr(), M, N, K, L.EPI_BIAS_GELU, b.data_ptr(), 1.0, o.data_ptr(), _s()))
+    ref = torch.nn.functional.gelu(y + b)
+    assert (o.float() - ref).abs().max().item() <= 0.01 * ref.abs().max().item() + 1e-3
 
 
 def test_gemm_f32_odd_n_and_padded_k():

@@ -107,6 +107,47 @@ def test_generate_sequence_with_esm3():
         m.generate_tokens([ESMProteinTensor(sequence=torch.tensor([0, 5, 6, 2]))], GenerationConfig(track="sequence"))
 
 
+def test_generate_and_batch_generate():
+    """ESM3.generate / batch_generate (reference esm3.py:377-412): per-prompt configs, error slots, num_steps
+    clamped to the prompt's masks, ESMProtein prompts through encode -> tokens -> decode."""
+    from esm_amd import synth
+    from esm_amd.api import ESMProtein, ESMProteinError, ESMProteinTensor
+    from esm_amd.esm3 import ESM3
+    from esm_amd.sampling import GenerationConfig
+    m = ESM3(128, 2, 8, 2)
+    m.load_state_dict(synth.esm3_weights(128, 2, 8, seed=51))
+    m = m.cuda()
+    det = dict(temperature=0.0, temperature_annealing=False, strategy="entropy")
+    seq_a = torch.tensor([0] + [32] * 20 + [2]).cuda()
+    seq_b = torch.tensor([0, 5, 6, 32, 32, 32, 7, 8, 32, 2]).cuda()
+    seq_c = torch.tensor([0, 5, 6, 7, 2]).cuda()  # nothing to decode
+    prompts = [ESMProteinTensor(sequence=seq_a), ESMProteinTensor(sequence=seq_b), ESMProteinTensor(sequence=seq_c),
+               ESMProteinTensor(sequence=seq_b.clone()), ESMProteinTensor(sequence=seq_b.clone())]
+    cfgs = [GenerationConfig(track="sequence", num_steps=4, **det), GenerationConfig(track="sequence", num_steps=8, **det),
+            GenerationConfig(track="sequence", num_steps=4, **det), GenerationConfig(track="structure", num_steps=2, **det),
+            GenerationConfig(track="coordinates")]
+    out = m.batch_generate(prompts, cfgs)
+    assert len(out) == 5
+    assert cfgs[1].num_steps == 4                      # 4 masked positions < 8 steps (generation.py:392-393)
+    assert isinstance(out[2], ESMProteinError) and "no masks" in out[2].error_msg and out[2].error_code == 500
+    assert isinstance(out[4], ESMProteinError) and "not supported" in out[4].error_msg
+    for i in (0, 1):
+        s_, p_ = out[i].sequence, prompts[i].sequence
+        assert not (s_ == 32).any() and torch.equal(s_[p_ != 32], p_[p_ != 32])
+    st = out[3].structure.cpu()
+    assert st[0] == 4098 and st[-1] == 4097 and (st[1:-1] < 4096).all() and torch.equal(out[3].sequence, seq_b)
+    # a prompt decoded in a batch with others == the same prompt decoded alone (deterministic settings)
+    alone = m.generate(ESMProteinTensor(sequence=seq_b.clone()), GenerationConfig(track="sequence", num_steps=8, **det))
+    assert (alone.sequence == out[1].sequence).float().mean() >= 0.9
+    # string prompt: '_' are masks (sequence tokenizer); comes back as a string of the same length without masks
+    prot = m.generate(ESMProtein(sequence="MK__LV_A"), GenerationConfig(track="sequence", num_steps=2, **det))
+    assert isinstance(prot, ESMProtein) and len(prot.sequence) == 8 and "_" not in prot.sequence
+    assert prot.sequence[:2] == "MK" and prot.sequence[4:6] == "LV" and prot.sequence[7] == "A"
+    assert m.batch_generate([], []) == []
+    with pytest.raises(AssertionError):
+        m.batch_generate(prompts[:2], cfgs[:1])
+
+
 def test_forward_and_sample():
     from esm_amd import synth
     from esm_amd.api import ESMProteinTensor, LogitsConfig
