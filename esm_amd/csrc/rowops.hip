@@ -157,7 +157,8 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
     }
 }
 
-template <int NU>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
+// LN = false (qk_layernorm=False block variant, attention.py:34-38): rotary and the q scale only.
+template <int NU, bool LN = true>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
 __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
                                                       const float* __restrict__ gk,
                                                       const int* __restrict__ positions,
@@ -210,27 +211,30 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
         }
         int pos = pos_next;
         if (tok + stride < M) load_tok(tok + stride);
-        st = wave_sum(st);
-        sk = wave_sum(sk);
-        const float mean_k = sk * inv_d, mean_q = (st - sk) * inv_d;
-        st = 0.f; sk = 0.f;
+        float rstd_k = 1.0f, rstd_q = q_scale;
+        if constexpr (LN) {
+            st = wave_sum(st);
+            sk = wave_sum(sk);
+            const float mean_k = sk * inv_d, mean_q = (st - sk) * inv_d;
+            st = 0.f; sk = 0.f;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const float m = kw[u] != 0.f ? mean_k : mean_q;
-            float s = 0.f;
+            for (int u = 0; u < NU; ++u) {
+                const float m = kw[u] != 0.f ? mean_k : mean_q;
+                float s = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                v[u][e] -= m;
-                s += v[u][e] * v[u][e];
+                for (int e = 0; e < 8; ++e) {
+                    v[u][e] -= m;
+                    s += v[u][e] * v[u][e];
+                }
+                if (u == NU - 1) s *= last_w;
+                st += s;
+                sk += s * kw[u];
             }
-            if (u == NU - 1) s *= last_w;
-            st += s;
-            sk += s * kw[u];
+            st = wave_sum(st);
+            sk = wave_sum(sk);
+            rstd_k = rsqrtf(sk * inv_d + eps);
+            rstd_q = rsqrtf((st - sk) * inv_d + eps) * q_scale;
         }
-        st = wave_sum(st);
-        sk = wave_sum(sk);
-        const float rstd_k = rsqrtf(sk * inv_d + eps);
-        const float rstd_q = rsqrtf((st - sk) * inv_d + eps) * q_scale;
         pos = pos < rope_len ? pos : rope_len - 1;  // host validates; clamp keeps the load in bounds
         const float* cs = rcos + (size_t)pos * 32 + j0;
         const float* sn = rsin + (size_t)pos * 32 + j0;
@@ -240,9 +244,13 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
         for (int u = 0; u < NU; ++u) {
             // every lane takes part in the exchange: the partner lane L^4 is in range whenever L is (nunits % 8 == 0)
             const bool isk = kw[u] != 0.f;
-            const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
             const float rs = isk ? rstd_k : rstd_q;
-            const f32x4 ga = *(const f32x4*)g * rs, gb = *(const f32x4*)(g + 4) * rs;
+            f32x4 ga = f32x4{rs, rs, rs, rs}, gb = ga;
+            if constexpr (LN) {
+                const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
+                ga = *(const f32x4*)g * rs;
+                gb = *(const f32x4*)(g + 4) * rs;
+            }
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -417,7 +425,10 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
                             const float* rsin, int rope_len, int M, int d, int H, float q_scale, float eps,
                             esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;
-    if (!qkv || !gq || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
+    if (!qkv || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
+    if ((gq == nullptr) != (gk == nullptr))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: gamma_q and gamma_k must both be given (QK-LayerNorm) or both be NULL");
+    const bool ln = gq != nullptr;
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
     const int nu = (16 * H + 63) / 64;
     if (nu > QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: too many heads (%d)", H);
@@ -430,8 +441,12 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
     do {                                                                                                       \
         static int cap = 0;                                                                                    \
         if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
-        hipLaunchKernelGGL(qk_prep_kernel<NU>, dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, gk, \
-                           positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                            \
+        if (ln)                                                                                                \
+            hipLaunchKernelGGL((qk_prep_kernel<NU, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, \
+                               gk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                    \
+        else                                                                                                   \
+            hipLaunchKernelGGL((qk_prep_kernel<NU, false>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, \
+                               gq, gk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                \
     } while (0)
     switch (nu) {
         case 1: QK_LAUNCH(1); break;

@@ -180,6 +180,124 @@ class TrunkEngine:
         return post, x, hid
 
 
+class VariantEngine:
+    """The block variants of the reference's UnifiedTransformerBlock that the fused trunk call does not cover
+    (blocks.py:73-115): bias=True, qk_layernorm=False, ffn_type="gelu", geometric attention with
+    mask_and_zero_frameless=False.  Same kernels, one C call per op instead of one per forward:
+
+        esmk_layernorm -> esmk_gemm(+bias) -> esmk_qk_prep (gammas NULL without QK-LayerNorm) -> esmk_attn_varlen
+          -> esmk_gemm(residual: x += (ctx.Wo^T + b) / s)
+        [esmk_layernorm -> esmk_gemm(f32) -> esmk_geom_attn_ex -> esmk_gemm(residual)]
+        esmk_layernorm -> esmk_gemm(SwiGLU | bias+GELU) -> esmk_gemm(residual)
+
+    Same interface as TrunkEngine.forward."""
+
+    def __init__(self, weights: dict, prefix: str, d_model: int, n_heads: int, n_layers: int, device,
+                 v_heads: int | None = None, n_layers_geom: int = 0, scale_residue: bool = True,
+                 expansion_ratio: float = 8 / 3, rope_len: int = 4096, mask_and_zero_frameless: bool = False,
+                 bias: bool = False, qk_layernorm: bool = True, ffn_type: str = "swiglu"):
+        if d_model != 64 * n_heads:
+            raise L.EsmkError(f"head dim must be 64 (d_model={d_model}, n_heads={n_heads})")
+        if bias and qk_layernorm:
+            raise L.EsmkError("biased q_ln / k_ln (bias=True with qk_layernorm=True) is not built")
+        self.lib = L.lib()
+        self.device = dev = torch.device(device)
+        self.d, self.H, self.n_layers, self.Hv = d_model, n_heads, n_layers, v_heads or 0
+        self.mzf, self.ffn_type = int(bool(mask_and_zero_frameless)), ffn_type
+        self.inv_s = 1.0 / (math.sqrt(n_layers / 36) if scale_residue else 1.0)
+        if ffn_type == "swiglu":
+            self.h = int(((expansion_ratio * d_model) + 255) // 256 * 256)
+        else:
+            self.h = int(expansion_ratio * d_model)
+            if self.h % 64:
+                raise L.EsmkError(f"GELU FFN hidden width {self.h} must be a multiple of 64 (the GEMM's K granule)")
+        f = lambda k: _f32(weights[prefix + k], dev)
+        ob = lambda k: _f32(weights[prefix + k], dev) if bias else None  # optional bias
+        self.layers = []
+        for i in range(n_layers):
+            b = f"blocks.{i}."
+            ly = dict(ln1_g=f(b + "attn.layernorm_qkv.0.weight"), ln1_b=f(b + "attn.layernorm_qkv.0.bias"),
+                      w_qkv=pack_weight(weights[prefix + b + "attn.layernorm_qkv.1.weight"], dev),
+                      b_qkv=ob(b + "attn.layernorm_qkv.1.bias"),
+                      gq=f(b + "attn.q_ln.weight") if qk_layernorm else None,
+                      gk=f(b + "attn.k_ln.weight") if qk_layernorm else None,
+                      w_o=pack_weight(weights[prefix + b + "attn.out_proj.weight"], dev), b_o=ob(b + "attn.out_proj.bias"),
+                      ln2_g=f(b + "ffn.0.weight"), ln2_b=f(b + "ffn.0.bias"),
+                      w1=pack_weight(weights[prefix + b + "ffn.1.weight"], dev,
+                                     L.PACK_SWIGLU if ffn_type == "swiglu" else L.PACK_PLAIN),
+                      b1=ob(b + "ffn.1.bias"),
+                      w2=pack_weight(weights[prefix + b + "ffn.3.weight"], dev), b2=ob(b + "ffn.3.bias"))
+            if ffn_type == "gelu" and ly["b1"] is None:  # the bias+GELU epilogue always takes a bias
+                ly["b1"] = torch.zeros(self.h, dtype=torch.float32, device=dev)
+            if i < n_layers_geom:
+                ly.update(sn_g=f(b + "geom_attn.s_norm.weight"), sn_b=ob(b + "geom_attn.s_norm.bias"),
+                          w_proj=pack_weight(weights[prefix + b + "geom_attn.proj.weight"], dev),
+                          b_proj=ob(b + "geom_attn.proj.bias"),
+                          w_out=pack_weight(weights[prefix + b + "geom_attn.out_proj.weight"], dev),
+                          b_out=ob(b + "geom_attn.out_proj.bias"),
+                          dist=f(b + "geom_attn.distance_scale_per_head"), rot=f(b + "geom_attn.rotation_scale_per_head"))
+            self.layers.append(ly)
+        self.norm_g = f("norm.weight")
+        self._set_rope(rope_len)
+
+    def _set_rope(self, n_pos: int):
+        cos, sin = rotary_tables(n_pos)
+        self._cos, self._sin, self.rope_len = cos.to(self.device), sin.to(self.device), n_pos
+
+    def forward(self, x: torch.Tensor, batch: DeviceBatch, want_post: bool = True, want_hiddens: bool = False):
+        """x f32 [N, d] (modified in place -> pre-norm output).  Returns (post_norm|None, x, hiddens|None)."""
+        N, d, H, Hv, h, lib, dev = batch.pb.n_tokens, self.d, self.H, self.Hv, self.h, self.lib, x.device
+        assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape == (N, d)
+        if batch.pb.max_position >= self.rope_len:
+            self._set_rope(max(2 * self.rope_len, batch.pb.max_position + 1))
+        post = torch.empty_like(x) if want_post else None
+        hid = torch.empty((self.n_layers, N, d), dtype=torch.float32, device=dev) if want_hiddens else None
+        if N == 0:
+            return post, x, hid
+        s = _stream()
+        bf = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        xb, qkv, ctx, hb = bf(N, d), bf(N, 3 * d), bf(N, d), bf(N, h)
+        q_scale = 0.125 * 1.4426950408889634  # 64^-1/2 * log2(e): the attention kernel exponentiates with exp2
+        ln = lambda g, b: L.check(lib.esmk_layernorm(L.ptr(x), L.F32, L.ptr(g), L.ptr(b), L.ptr(xb), L.BF16, N, d, 1e-5, s),
+                                  "esmk_layernorm")
+        gemm = lambda a, lda, w, n, k, epi, b, alpha, out: L.check(
+            lib.esmk_gemm(L.ptr(a), lda, L.ptr(w), N, n, k, epi, L.ptr(b), alpha, L.ptr(out), s), "esmk_gemm")
+        for i, ly in enumerate(self.layers):
+            ln(ly["ln1_g"], ly["ln1_b"])
+            gemm(xb, d, ly["w_qkv"], 3 * d, d, L.EPI_BF16, ly["b_qkv"], 1.0, qkv)
+            L.check(lib.esmk_qk_prep(L.ptr(qkv), L.ptr(ly["gq"]), L.ptr(ly["gk"]), L.ptr(batch.positions), L.ptr(self._cos),
+                                     L.ptr(self._sin), self.rope_len, N, d, H, q_scale, 1e-5, s), "esmk_qk_prep")
+            L.check(lib.esmk_attn_varlen(L.ptr(qkv), L.ptr(ctx), L.ptr(batch.cu_seqlens), L.ptr(batch.qblk_map),
+                                         batch.desc.n_qblk, N, d, H, s), "esmk_attn_varlen")
+            gemm(ctx, d, ly["w_o"], d, d, L.EPI_RESIDUAL, ly["b_o"], self.inv_s, x)
+            if "w_proj" in ly:
+                if batch.affine is None or batch.affine_mask is None or batch.chain_id is None:
+                    raise ValueError("affine, affine_mask and chain_id are required by the geometric-attention block")
+                ldg = (3 * Hv + 63) // 64 * 64
+                proj = torch.empty((N, 15 * Hv), dtype=torch.float32, device=dev)
+                go = bf(N, ldg)
+                scratch = torch.empty(lib.esmk_geom_scratch_bytes(N, Hv), dtype=torch.uint8, device=dev)
+                ln(ly["sn_g"], ly["sn_b"])
+                gemm(xb, d, ly["w_proj"], 15 * Hv, d, L.EPI_F32, ly["b_proj"], 1.0, proj)
+                L.check(lib.esmk_geom_attn_ex(L.ptr(proj), L.ptr(batch.affine), L.ptr(batch.affine_mask), L.ptr(batch.seq_id),
+                                              L.ptr(batch.chain_id), L.ptr(batch.row_cu), batch.pb.B, batch.pb.max_row_len,
+                                              L.ptr(ly["dist"]), L.ptr(ly["rot"]), L.ptr(go), ldg, L.ptr(scratch), N, Hv,
+                                              self.mzf, s), "esmk_geom_attn_ex")
+                gemm(go, ldg, ly["w_out"], d, 3 * Hv, L.EPI_RESIDUAL, ly["b_out"], self.inv_s, x)
+            ln(ly["ln2_g"], ly["ln2_b"])
+            if self.ffn_type == "swiglu":
+                gemm(xb, d, ly["w1"], 2 * h, d, L.EPI_SWIGLU, ly["b1"], 1.0, hb)
+            else:
+                gemm(xb, d, ly["w1"], h, d, L.EPI_BIAS_GELU, ly["b1"], 1.0, hb)
+            gemm(hb, h, ly["w2"], d, h, L.EPI_RESIDUAL, ly["b2"], self.inv_s, x)
+            if hid is not None:
+                hid[i].copy_(x)
+        if post is not None:
+            L.check(lib.esmk_layernorm(L.ptr(x), L.F32, L.ptr(self.norm_g), None, L.ptr(post), L.F32, N, d, 1e-5, s),
+                    "esmk_layernorm")
+        return post, x, hid
+
+
 def segment_mean(x: torch.Tensor, cu: torch.Tensor) -> torch.Tensor:
     """Mean of x f32 [N, d] over the row ranges cu int32 [S+1] (device) -> [S, d] (esmk_segment_mean)."""
     assert x.is_cuda and x.dtype == torch.float32 and x.stride(-1) == 1 and cu.dtype == torch.int32

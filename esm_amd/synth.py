@@ -187,6 +187,27 @@ def fdec_weights(d: int, n_layers: int, n_keywords: int, n_interpro: int, seed: 
     return out
 
 
+def stack_variant_weights(shapes: dict, seed: int = 0) -> dict:
+    """Unit-scale weights for a TransformerStack of ANY block variant (blocks.py:73-115) from a {key: shape} map -
+    normally the module's own state_dict shapes, so the same call works for the reference's module and for ours.
+    LayerNorm weights ~ N(1, 0.1), every bias ~ N(0, 0.1), per-head geometric scales ~ N(0, 0.5), matrices
+    ~ N(0, 1/fan_in)."""
+    out = {}
+    for name, shape in shapes.items():
+        shape = tuple(shape)
+        is_ln = any(t in name for t in (".layernorm_qkv.0.", ".ffn.0.", ".q_ln.", ".k_ln.", ".s_norm.")) or name.endswith("norm.weight")
+        if is_ln:
+            mean, std = (1.0, 0.1) if name.endswith("weight") else (0.0, 0.1)
+        elif name.endswith(".bias"):
+            mean, std = 0.0, 0.1
+        elif name.endswith("_scale_per_head"):
+            mean, std = 0.0, 0.5
+        else:
+            mean, std = 0.0, float(shape[-1]) ** -0.5
+        out[name] = _draw(name, shape, seed, mean, std)
+    return out
+
+
 def make_weights(shapes: dict, seed: int = 0) -> dict:
     out = {}
     for name, shape in shapes.items():

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from . import _lib as L
 from .affine3d import Affine3D
-from .engine import DeviceBatch, TrunkEngine
+from .engine import DeviceBatch, TrunkEngine, VariantEngine
 from .packing import PackedBatch, pack_sequence_id
 
 
@@ -25,52 +25,69 @@ class _Params(nn.Module):
         raise L.EsmkError("parameter container: the forward pass runs in the HIP engine")
 
 
-class _Attn(_Params):
-    def __init__(self, d):
+class _Attn(_Params):  # MultiHeadAttention, attention.py:17-38
+    def __init__(self, d, bias=False, qk_layernorm=True):
         super().__init__()
-        self.layernorm_qkv = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 3 * d, bias=False))
-        self.out_proj = nn.Linear(d, d, bias=False)
-        self.q_ln = nn.LayerNorm(d, bias=False)
-        self.k_ln = nn.LayerNorm(d, bias=False)
+        self.layernorm_qkv = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 3 * d, bias=bias))
+        self.out_proj = nn.Linear(d, d, bias=bias)
+        self.q_ln = nn.LayerNorm(d, bias=bias) if qk_layernorm else nn.Identity()
+        self.k_ln = nn.LayerNorm(d, bias=bias) if qk_layernorm else nn.Identity()
 
 
-class _Geom(_Params):
-    def __init__(self, d, v_heads):
+class _Geom(_Params):  # GeometricReasoningOriginalImpl, geom_attention.py:10-50
+    def __init__(self, d, v_heads, bias=False):
         super().__init__()
-        self.s_norm = nn.LayerNorm(d, bias=False)
-        self.proj = nn.Linear(d, 15 * v_heads, bias=False)
-        self.out_proj = nn.Linear(3 * v_heads, d, bias=False)
+        self.s_norm = nn.LayerNorm(d, bias=bias)
+        self.proj = nn.Linear(d, 15 * v_heads, bias=bias)
+        self.out_proj = nn.Linear(3 * v_heads, d, bias=bias)
         self.distance_scale_per_head = nn.Parameter(torch.zeros(v_heads))
         self.rotation_scale_per_head = nn.Parameter(torch.zeros(v_heads))
 
 
-class _Block(_Params):
-    def __init__(self, d, h, v_heads, geom):
+class _Block(_Params):  # UnifiedTransformerBlock, blocks.py:73-115
+    def __init__(self, d, v_heads, geom, bias=False, qk_layernorm=True, ffn_type="swiglu", expansion_ratio=8 / 3):
         super().__init__()
-        self.attn = _Attn(d)
+        self.attn = _Attn(d, bias, qk_layernorm)
         if geom:
-            self.geom_attn = _Geom(d, v_heads)
-        self.ffn = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 2 * h, bias=False), nn.Identity(),
-                                 nn.Linear(h, d, bias=False))
+            self.geom_attn = _Geom(d, v_heads, bias)
+        if ffn_type == "swiglu":
+            h = swiglu_correction_fn(expansion_ratio, d)
+            self.ffn = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, 2 * h, bias=bias), nn.Identity(),
+                                     nn.Linear(h, d, bias=bias))
+        elif ffn_type == "gelu":
+            h = int(expansion_ratio * d)
+            self.ffn = nn.Sequential(nn.LayerNorm(d), nn.Linear(d, h, bias=bias), nn.Identity(), nn.Linear(h, d, bias=bias))
+        else:
+            raise ValueError(f"Unknown ffn_type: {ffn_type}")
 
 
 class TransformerStack(nn.Module):
+    """Every constructor option of the reference (transformer_stack.py:26-62).  The ESM C / ESM3 variant (bias=False,
+    qk_layernorm=True, ffn_type="swiglu", geometric blocks with mask_and_zero_frameless=True) runs as ONE C call
+    (`esmk_trunk_forward`, fused residual deltas); the other block variants of blocks.py:73-115 run block by block over
+    the same kernels (`engine.VariantEngine`).  Not built: bias=True together with qk_layernorm=True (q_ln / k_ln
+    would then carry a bias, attention.py:32-33; no model of the reference uses that combination)."""
+
     def __init__(self, d_model: int, n_heads: int, v_heads: int | None, n_layers: int, n_layers_geom: int = 1,
                  scale_residue: bool = True, mask_and_zero_frameless: bool = False, bias: bool = False,
                  qk_layernorm: bool = True, ffn_type: str = "swiglu", expansion_ratio: float = 8 / 3,
                  use_flash_attn: bool = False):
         super().__init__()
-        if bias or not qk_layernorm or ffn_type != "swiglu":
-            raise NotImplementedError("esm_amd builds the ESM C / ESM3 trunk variant only: bias=False, "
-                                      "qk_layernorm=True, ffn_type='swiglu' (SURVEY.md 8f lists the others as next)")
-        if n_layers_geom > 0 and not mask_and_zero_frameless:
-            raise NotImplementedError("geometric attention is built with mask_and_zero_frameless=True (ESM3)")
+        if bias and qk_layernorm:
+            raise NotImplementedError("bias=True with qk_layernorm=True (biased q_ln / k_ln) is not built: no model of "
+                                      "the reference uses it")
+        if ffn_type not in ("swiglu", "gelu"):
+            raise ValueError(f"Unknown ffn_type: {ffn_type}")
         if n_layers_geom > 0 and v_heads is None:
             raise ValueError("v_heads must be specified when use_geom_attn is True")
         self.d_model, self.n_heads, self.v_heads, self.n_layers = d_model, n_heads, v_heads, n_layers
         self.n_layers_geom, self.scale_residue, self.expansion_ratio = n_layers_geom, scale_residue, expansion_ratio
-        h = swiglu_correction_fn(expansion_ratio, d_model)
-        self.blocks = nn.ModuleList([_Block(d_model, h, v_heads, i < n_layers_geom) for i in range(n_layers)])
+        self.mask_and_zero_frameless, self.bias, self.qk_layernorm, self.ffn_type = \
+            mask_and_zero_frameless, bias, qk_layernorm, ffn_type
+        # the fused whole-trunk call covers the ESM C / ESM3 variant; everything else goes block by block
+        self.fused = (not bias) and qk_layernorm and ffn_type == "swiglu" and (n_layers_geom == 0 or mask_and_zero_frameless)
+        self.blocks = nn.ModuleList([_Block(d_model, v_heads, i < n_layers_geom, bias, qk_layernorm, ffn_type,
+                                            expansion_ratio) for i in range(n_layers)])
         self.norm = nn.LayerNorm(d_model, bias=False)
         self._engine = None
         self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
@@ -88,9 +105,12 @@ class TransformerStack(nn.Module):
             dev = self.norm.weight.device
             if dev.type != "cuda":
                 raise L.EsmkError("esm_amd runs on the GPU only: move the module to cuda (there is no CPU path)")
-            self._engine = TrunkEngine(dict(self.state_dict()), "", self.d_model, self.n_heads, self.n_layers, dev,
-                                       v_heads=self.v_heads, n_layers_geom=self.n_layers_geom,
-                                       scale_residue=self.scale_residue, expansion_ratio=self.expansion_ratio)
+            cls = TrunkEngine if self.fused else VariantEngine
+            extra = {} if self.fused else dict(mask_and_zero_frameless=self.mask_and_zero_frameless, bias=self.bias,
+                                               qk_layernorm=self.qk_layernorm, ffn_type=self.ffn_type)
+            self._engine = cls(dict(self.state_dict()), "", self.d_model, self.n_heads, self.n_layers, dev,
+                               v_heads=self.v_heads, n_layers_geom=self.n_layers_geom,
+                               scale_residue=self.scale_residue, expansion_ratio=self.expansion_ratio, **extra)
         return self._engine
 
     # -- packed entry point (ESMC / the data-parallel runner) --------------------------------------

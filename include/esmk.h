@@ -118,6 +118,8 @@ int esmk_gemm_ws(const void* A_bf16, int lda, const void* W_packed, int M, int N
  * positions int32 [M]: rotary position of each token (column index in the reference's [B,L] row).
  * rope_cos / rope_sin f32 [rope_len, 32] (angles computed in fp32 as rotary.py:136-181 does).
  * q is additionally multiplied by q_scale (softmax scale * log2(e)) so the attention kernel uses exp2.
+ * gamma_q = gamma_k = NULL: the qk_layernorm=False block variant (attention.py:34-38: q_ln / k_ln are Identity) -
+ * rotary and the q scale only.
  * ------------------------------------------------------------------------------------------ */
 int esmk_qk_prep(void* qkv_bf16, const float* gamma_q, const float* gamma_k, const int32_t* positions,
                  const float* rope_cos, const float* rope_sin, int rope_len, int M, int d, int n_heads,

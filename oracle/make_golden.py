@@ -90,6 +90,50 @@ def stack_case(name, d, H, NL, L, wseed, scale_residue=True):
          post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4, scale_residue=int(scale_residue))
 
 
+def stack_variant_case(name, d, H, NL, L, wseed, VH=None, **kw):
+    """TransformerStack with the other block variants of blocks.py:73-115 (bias / no QK-LayerNorm / GELU FFN /
+    geometric attention without frameless zeroing): input activations (+ coordinates, chains) -> (post, pre).
+    Weights: synth.stack_variant_weights over the reference module's own state_dict shapes."""
+    m = ref_import.build_stack_variant(d, H, NL, VH, **kw)
+    w = synth.stack_variant_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=wseed)
+    m.load_state_dict(w, strict=True)
+    g = torch.Generator().manual_seed(wseed + 17)
+    x = torch.randn(2, L, d, generator=g)
+    sid = torch.zeros(2, L, dtype=torch.int64)
+    sid[0, L // 2:] = 1          # row 0: two bin-packed sequences
+    sid[1, L - 7:] = 5           # row 1: one sequence + a run of padding with its own id
+    arrays = dict(kind="stack_variant", d=d, H=H, NL=NL, VH=VH or 0, wseed=wseed, x=_np(x), sequence_id=_np(sid),
+                  ctor=repr(sorted(kw.items())))
+    affine = mask = chain = None
+    if kw.get("n_layers_geom", 1) > 0:
+        from esm.utils.structure.affine3d import build_affine3d_from_coordinates
+        coords = synth.synth_backbone(2, L, seed=wseed + 4, nan_frac=0.2)
+        chain = torch.zeros(2, L, dtype=torch.int64)
+        chain[1, L // 3:] = 1
+        affine, mask = build_affine3d_from_coordinates(coords)
+        arrays.update(coords=_np(coords), chain_id=_np(chain))
+    with torch.no_grad():
+        post, pre, hid = m(x, sequence_id=sid, affine=affine, affine_mask=mask, chain_id=chain)
+    save(name, post=_np(post), pre=_np(pre), hidden0=_np(hid[0]), **arrays)
+
+
+STACK_VARIANTS = {  # name -> (d, H, NL, L, wseed, VH, constructor options)
+    "stackvar_bias_noqkln_gelu": (128, 2, 2, 40, 81, None, dict(n_layers_geom=0, bias=True, qk_layernorm=False,
+                                                                  ffn_type="gelu", expansion_ratio=4.0)),
+    "stackvar_noqkln_swiglu": (128, 2, 3, 40, 82, None, dict(n_layers_geom=0, qk_layernorm=False)),
+    "stackvar_gelu_noscale": (192, 3, 2, 33, 83, None, dict(n_layers_geom=0, ffn_type="gelu", expansion_ratio=2.0,
+                                                            scale_residue=False)),
+    "stackvar_geom_nozero": (128, 2, 2, 40, 84, 8, dict(n_layers_geom=1, mask_and_zero_frameless=False)),
+    "stackvar_bias_geom2": (128, 2, 2, 40, 85, 8, dict(n_layers_geom=2, bias=True, qk_layernorm=False, ffn_type="gelu",
+                                                        expansion_ratio=4.0, mask_and_zero_frameless=True)),
+}
+
+
+def stack_variant_cases():
+    for name, (d, H, NL, L, wseed, VH, kw) in STACK_VARIANTS.items():
+        stack_variant_case(name, d, H, NL, L, wseed, VH=VH, **kw)
+
+
 def vqdec_tokens(lengths, L, seed):
     """Structure tokens [B, L]: BOS, codes (with one MASK and one CHAINBREAK inside row 0), EOS, PAD after."""
     g = torch.Generator().manual_seed(seed)
@@ -457,6 +501,8 @@ def main():
         return vqenc_cases()
     if "--fdec-only" in sys.argv:
         return fdec_cases()
+    if "--stack-variants-only" in sys.argv:
+        return stack_variant_cases()
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -514,6 +560,8 @@ def main():
     vqenc_cases()
     # (ix) function-token decoder forward (block variant bias=True, qk_layernorm=False, GELU FFN, head dim 128)
     fdec_cases()
+    # (x) the remaining block variants through the generic TransformerStack
+    stack_variant_cases()
 
 
 if __name__ == "__main__":

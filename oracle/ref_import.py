@@ -97,6 +97,14 @@ def build_stack(d_model, n_heads, n_layers, weights: dict, v_heads=None, n_layer
     return m
 
 
+def build_stack_variant(d_model, n_heads, n_layers, v_heads=None, **kw):
+    """The reference's TransformerStack with any constructor options (weights are loaded by the caller)."""
+    install()
+    from esm.layers.transformer_stack import TransformerStack
+
+    return TransformerStack(d_model, n_heads, v_heads, n_layers, **kw).eval()
+
+
 def build_vqdec(d_model, n_heads, n_layers, weights: dict):
     install()
     from esm.models.vqvae import StructureTokenDecoder

@@ -188,27 +188,33 @@ def geometric_attention(s, rot, trans, affine_mask, sequence_id, chain_id, w, pr
     return _linear(o, w, prefix + "out_proj")
 
 
-def transformer_block(x, sequence_id, frames, chain_id, w, prefix, n_heads, v_heads, scale, geom):
-    """esm/layers/blocks.py:146-157."""
+def transformer_block(x, sequence_id, frames, chain_id, w, prefix, n_heads, v_heads, scale, geom,
+                      ffn_type="swiglu", mask_and_zero_frameless=True):
+    """esm/layers/blocks.py:146-157 (ffn_type: blocks.py:109-114)."""
     x = x + multi_head_attention(x, sequence_id, w, prefix + "attn.", n_heads) / scale
     if geom:
         rot, trans, fmask = frames
-        x = x + geometric_attention(x, rot, trans, fmask, sequence_id, chain_id, w, prefix + "geom_attn.", v_heads) / scale
-    x = x + swiglu_ffn(x, w, prefix + "ffn.") / scale
+        x = x + geometric_attention(x, rot, trans, fmask, sequence_id, chain_id, w, prefix + "geom_attn.", v_heads,
+                                    mask_and_zero_frameless=mask_and_zero_frameless) / scale
+    ffn = swiglu_ffn if ffn_type == "swiglu" else gelu_ffn
+    x = x + ffn(x, w, prefix + "ffn.") / scale
     return x
 
 
 def transformer_stack(x, sequence_id, w, prefix, n_heads, n_layers, v_heads=None, n_layers_geom=0,
-                      frames=None, chain_id=None, scale_residue=True):
+                      frames=None, chain_id=None, scale_residue=True, ffn_type="swiglu", mask_and_zero_frameless=True):
     """esm/layers/transformer_stack.py:64-94 -> (post_norm, pre_norm, hiddens).  scale_residue=False is the
-    VQ-VAE structure decoder's stack (esm/models/vqvae.py:337-339)."""
+    VQ-VAE structure decoder's stack (esm/models/vqvae.py:337-339).  bias=True / qk_layernorm=False are read off
+    the weight dict (keys present or not); ffn_type and mask_and_zero_frameless are constructor options
+    (transformer_stack.py:34-37) and passed in."""
     if chain_id is None:
         chain_id = torch.ones(x.shape[:-1], dtype=torch.int64)
     scale = residue_scale(n_layers) if scale_residue else 1.0
     hiddens = []
     for i in range(n_layers):
         x = transformer_block(x, sequence_id, frames, chain_id, w, f"{prefix}blocks.{i}.", n_heads,
-                              v_heads, scale, geom=i < n_layers_geom)
+                              v_heads, scale, geom=i < n_layers_geom, ffn_type=ffn_type,
+                              mask_and_zero_frameless=mask_and_zero_frameless)
         hiddens.append(x)
     return layer_norm(x, w[prefix + "norm.weight"]), x, hiddens
 

@@ -41,7 +41,19 @@ def weights_for(fx):
         return synth.vqenc_weights(d, int(fx["VH"]), int(fx["NL"]), 128, int(fx["n_codes"]), seed=ws)
     if kind == "fdec":
         return synth.fdec_weights(d, int(fx["NL"]), int(fx["n_kw"]), int(fx["n_ip"]), seed=ws)
+    if kind == "stack_variant":
+        # shapes from OUR module's state_dict: the fixture's weights were drawn over the REFERENCE module's keys
+        # and shapes, so this also pins the state_dict contract of every block variant
+        from esm_amd.transformer_stack import TransformerStack
+        m = TransformerStack(d, int(fx["H"]), int(fx["VH"]) or None, int(fx["NL"]), **variant_ctor(fx))
+        return synth.stack_variant_weights({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed=ws)
     raise ValueError(kind)
+
+
+def variant_ctor(fx) -> dict:
+    """Constructor options of a stack_variant fixture (stored as repr(sorted(kwargs.items())))."""
+    import ast
+    return dict(ast.literal_eval(str(fx["ctor"])))
 
 
 def cosine_min(a, b):

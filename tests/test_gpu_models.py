@@ -67,6 +67,38 @@ def test_stack_vs_golden(name):
     assert len(hid) == int(fx["NL"])
 
 
+@pytest.mark.parametrize("name", ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale",
+                                  "stackvar_geom_nozero", "stackvar_bias_geom2"])
+def test_stack_variants_vs_golden(name):
+    """The generic TransformerStack with the reference's other constructor options (bias, qk_layernorm=False, GELU FFN,
+    geometric blocks with / without frameless zeroing) against outputs of the reference's own TransformerStack."""
+    from esm_amd.affine3d import build_affine3d_from_coordinates
+    from esm_amd.transformer_stack import TransformerStack
+    fx = G.load(name)
+    kw = G.variant_ctor(fx)
+    m = TransformerStack(int(fx["d"]), int(fx["H"]), int(fx["VH"]) or None, int(fx["NL"]), **kw)
+    assert not m.fused
+    m.load_state_dict(G.weights_for(fx), strict=True)
+    m = m.cuda()
+    aff = mask = chain = None
+    if kw.get("n_layers_geom", 1) > 0:
+        aff, mask = build_affine3d_from_coordinates(G.t(fx["coords"]).cuda())
+        chain = G.t(fx["chain_id"]).cuda()
+    post, pre, hid = m(G.t(fx["x"]).cuda(), G.t(fx["sequence_id"]).cuda(), aff, mask, chain)
+    emb_ok(post.cpu(), G.t(fx["post"]))
+    emb_ok(pre.cpu(), G.t(fx["pre"]))
+    emb_ok(hid[0].cpu(), G.t(fx["hidden0"]))
+    assert len(hid) == int(fx["NL"])
+
+
+def test_stack_variant_not_built():
+    from esm_amd.transformer_stack import TransformerStack
+    with pytest.raises(NotImplementedError):
+        TransformerStack(128, 2, None, 2, n_layers_geom=0, bias=True, qk_layernorm=True)
+    with pytest.raises(ValueError):
+        TransformerStack(128, 2, None, 2, n_layers_geom=0, ffn_type="relu")
+
+
 def test_frames_vs_golden():
     from esm_amd.affine3d import build_affine3d_from_coordinates
     fx = G.load("frames")

@@ -43,6 +43,30 @@ def test_stack(name):
     _close(pre[:, ::s][valid], G.t(fx["pre"])[valid])
 
 
+STACK_VARIANTS = ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale", "stackvar_geom_nozero",
+                  "stackvar_bias_geom2"]
+
+
+@pytest.mark.parametrize("name", STACK_VARIANTS)
+def test_stack_variants(name):
+    """The other block variants of blocks.py:73-115 through the reference's generic TransformerStack."""
+    fx = G.load(name)
+    w = G.weights_for(fx)
+    kw = G.variant_ctor(fx)
+    frames = chain = None
+    ng = kw.get("n_layers_geom", 1)
+    if ng > 0:
+        frames = trunk_ref.build_frames(G.t(fx["coords"]))
+        chain = G.t(fx["chain_id"])
+    post, pre, hid = trunk_ref.transformer_stack(
+        G.t(fx["x"]), G.t(fx["sequence_id"]), w, "", int(fx["H"]), int(fx["NL"]), v_heads=int(fx["VH"]) or None,
+        n_layers_geom=ng, frames=frames, chain_id=chain, scale_residue=kw.get("scale_residue", True),
+        ffn_type=kw.get("ffn_type", "swiglu"), mask_and_zero_frameless=kw.get("mask_and_zero_frameless", False))
+    _close(post, G.t(fx["post"]), 5e-5)
+    _close(pre, G.t(fx["pre"]), 5e-5)
+    _close(hid[0], G.t(fx["hidden0"]), 5e-5)
+
+
 def test_frames():
     fx = G.load("frames")
     rot, trans, mask = trunk_ref.build_frames(G.t(fx["coords"]))
