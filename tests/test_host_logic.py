@@ -118,9 +118,27 @@ def test_cpu_module_fails_loudly_without_gpu_path():
         m(torch.zeros(1, 4, dtype=torch.long))
 
 
-def test_unsupported_variants_rejected():
+def test_block_variants_state_dict_and_rejections():
+    """Every constructor option of the reference's TransformerStack builds the reference's state_dict keys (the
+    fixtures' weights were drawn over the REFERENCE module's keys / shapes: tests/_golden.py weights_for); the one
+    combination that is not built is rejected at construction."""
     from esm_amd.transformer_stack import TransformerStack
+    from tests import _golden as G
+    for name in ("stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale", "stackvar_geom_nozero",
+                 "stackvar_bias_geom2"):
+        fx = G.load(name)
+        m = TransformerStack(int(fx["d"]), int(fx["H"]), int(fx["VH"]) or None, int(fx["NL"]), **G.variant_ctor(fx))
+        m.load_state_dict(G.weights_for(fx), strict=True)
+        assert not m.fused
+    m = TransformerStack(128, 2, None, 1, n_layers_geom=0, bias=True, qk_layernorm=False, ffn_type="gelu", expansion_ratio=4.0)
+    keys = set(m.state_dict())
+    assert "blocks.0.attn.out_proj.bias" in keys and "blocks.0.ffn.1.bias" in keys and "blocks.0.attn.q_ln.weight" not in keys
+    assert m.state_dict()["blocks.0.ffn.1.weight"].shape == (512, 128)
+    assert TransformerStack(128, 2, 8, 2, n_layers_geom=1, mask_and_zero_frameless=True).fused
+    assert TransformerStack(128, 2, None, 2, n_layers_geom=0).fused
     with pytest.raises(NotImplementedError):
-        TransformerStack(128, 2, None, 1, n_layers_geom=0, bias=True)
-    with pytest.raises(NotImplementedError):
-        TransformerStack(128, 2, None, 1, n_layers_geom=0, ffn_type="gelu")
+        TransformerStack(128, 2, None, 1, n_layers_geom=0, bias=True)  # biased q_ln / k_ln
+    with pytest.raises(ValueError):
+        TransformerStack(128, 2, None, 1, n_layers_geom=0, ffn_type="relu")
+    with pytest.raises(ValueError):
+        TransformerStack(128, 2, None, 1, n_layers_geom=1)  # v_heads missing
