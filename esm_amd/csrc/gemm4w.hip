@@ -207,7 +207,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const int q4 = (lane >> 4) * 4;
     constexpr bool kBf16Out = (EPI == ESMK_EPI_BF16 || EPI == ESMK_EPI_SWIGLU || EPI == ESMK_EPI_BIAS_GELU);
     const int OW = (EPI == ESMK_EPI_SWIGLU) ? (N >> 1) : N;  // output width
-    if (kBf16Out && (OW & 7) == 0) {
+    // bf16 outputs always take the staged path: esmk_gemm4w sends widths that are not multiples of 8 (rows not 16-byte
+    // aligned) to the eight-wave kernel.  ONE epilogue path per instantiation also keeps the register allocator from
+    // splitting an accumulator's live range through VGPRs inside the K loop (seen with two paths: a v_accvgpr_read at
+    // the loop head straight behind the opaque MFMAs of the previous iteration).
+    if constexpr (kBf16Out) {
         // bf16 outputs: stage this wave's 128-token x CW-channel block through its own LDS region (no wave reads
         // fragments after barrier Q of the last tile, and every DMA was retired at its barrier P) and store whole
         // rows, 16 B per lane.  No inter-wave synchronisation needed.
@@ -269,7 +273,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             if (t < M && cc < OW) *(u32x4*)((__bf16*)out + (size_t)t * OW + cc) = v;
         }
         return;
-    }
+    } else {
 #pragma unroll
     for (int ni = 0; ni < 8; ++ni) {
         __builtin_amdgcn_sched_barrier(0);
@@ -289,6 +293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 for (int mi = 0; mi < 4; ++mi) epi_store4<EPI>(acc[h][mi][ni], t, cb + mi * 16 + q4, N, bias, alpha, out);
             }
         }
+    }
     }
 }
 
@@ -320,9 +325,15 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, const flo
 
 }  // namespace
 
-// Same contract as esmk_gemm256 (gemm256.hip).
+int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                 float alpha, void* out, hipStream_t s, int n_ctile);
+
+// Same contract as esmk_gemm256 (gemm256.hip), which also takes the bf16-output widths that are not multiples of 8.
 int esmk_gemm4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                 float alpha, void* out, hipStream_t s, int n_ctile) {
+    const bool bf16_out = epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU || epilogue == ESMK_EPI_BIAS_GELU;
+    const int ow = epilogue == ESMK_EPI_SWIGLU ? (N >> 1) : N;
+    if (bf16_out && (ow & 7)) return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
     switch (epilogue) {
         case ESMK_EPI_BF16: return launch<ESMK_EPI_BF16>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         case ESMK_EPI_F32: return launch<ESMK_EPI_F32>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
