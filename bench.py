@@ -36,6 +36,10 @@ PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
 # HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction for
 # 16-B/lane streams] + WRITE_SIZE, KiB -> bytes): profiles/r01_pmc_gemm_ffn1.json.  Algorithmic bytes: 291 MB.
 DOMINANT_KERNEL_HBM_BYTES = 880_983_979
+# Fraction of cycles the MFMA pipes are busy during that kernel, at the clock the chip held (rocprofv3 --pmc
+# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) over this very bench: tools/pmc_mfma_util.py,
+# profiles/r01_pmc_mfma_util.json; whole run incl. weight packing: 0.425)
+DOMINANT_KERNEL_MFMA_BUSY = 0.5914
 
 
 def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
@@ -195,7 +199,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
                          "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
                          "traffic": DOMINANT_KERNEL_HBM_BYTES, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_gemm_ffn1.json)",
-                         "launch_ms": kt * 1e3},
+                         "launch_ms": kt * 1e3,
+                         "mfma_busy_frac_at_held_clock": DOMINANT_KERNEL_MFMA_BUSY,
+                         "mfma_busy_source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE "
+                                             "(profiles/r01_pmc_mfma_util.json)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)

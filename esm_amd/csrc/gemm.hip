@@ -270,6 +270,8 @@ int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int
                  float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                 float alpha, void* out, hipStream_t s, int n_ctile);
+int esmk_gemm4v(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
@@ -280,7 +282,9 @@ int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, in
 static int gemm256_or_4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                          float alpha, void* out, hipStream_t s, int n_ctile) {
     const char* e = getenv("ESMK_GEMM_4W");
-    if (e && atoi(e)) return esmk_gemm4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
+    const int v = e ? atoi(e) : 0;
+    if (v == 2) return esmk_gemm4v(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);  // VGPR-staged operands
+    if (v) return esmk_gemm4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
     return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
 }
 

@@ -42,11 +42,11 @@ def test_gemm_bf16_and_f32(M, N, K):
 
 @pytest.mark.parametrize("M,N,K,swiglu", [(8192, 2304, 256, False), (8000, 2560, 192, False), (8192, 4608, 128, True),
                                             (5000, 6144, 1152, True), (70000, 1152, 320, False)])
-@pytest.mark.parametrize("persist,fourw", [("0", "0"), ("1", "0"), ("0", "1")])
+@pytest.mark.parametrize("persist,fourw", [("0", "0"), ("1", "0"), ("0", "1"), ("0", "2")])
 def test_gemm_many_tiles(M, N, K, swiglu, persist, fourw, monkeypatch):
     """More 256x256 tiles than CUs, ragged M, a ragged channel tile, 2..18 K-tiles - on the default kernel, on
     the persistent one (several tiles per workgroup, cross-tile prefetch, store-aware vmcnt) and on the four-wave
-    128x128-wave-tile kernel (gemm4w.hip)."""
+    128x128-wave-tile kernels (gemm4w.hip: LDS-DMA; gemm4v.hip: operands staged through VGPRs)."""
     monkeypatch.setenv("ESMK_GEMM_PERSIST", persist)
     monkeypatch.setenv("ESMK_GEMM_4W", fourw)
     L, lib, engine = _env()
@@ -69,7 +69,7 @@ def test_gemm_many_tiles(M, N, K, swiglu, persist, fourw, monkeypatch):
     assert err <= 0.01 * ref.abs().max().item() + 1e-3, err
 
 
-@pytest.mark.parametrize("fourw", ["0", "1"])
+@pytest.mark.parametrize("fourw", ["0", "1", "2"])
 @pytest.mark.parametrize("M,N,K", [(8192, 1024, 64), (9000, 1100, 192)])
 def test_gemm_256_tile_other_epilogues(M, N, K, fourw, monkeypatch):
     """fp32 (+bias), residual and bias+GELU epilogues of the two 256-tile kernels on problems big enough to reach
