@@ -33,6 +33,20 @@ void esmk_set_error(const char* fmt, ...);
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Kernels that need more than 64 KiB of dynamic LDS must be told so once PER DEVICE (the attribute belongs to the
+// device's copy of the code object).  `done` is a per-kernel bit mask of devices already set up; a lost race between
+// threads only repeats the (idempotent) call.  Returns false when the runtime refuses.
+#include <atomic>
+static inline bool esmk_reserve_lds(const void* kernel, int bytes, std::atomic<unsigned long long>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    const unsigned long long bit = (dev >= 0 && dev < 64) ? (1ull << dev) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    if (bit) done.fetch_or(bit, std::memory_order_release);
+    return true;
+}
+
 // ---- bf16 <-> f32 (round-to-nearest-even through the hardware cvt; NaN stays NaN) ----
 __device__ __forceinline__ float bf16_bits_to_f32(unsigned short u) {
     return __uint_as_float(((unsigned int)u) << 16);

@@ -187,12 +187,9 @@ int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     const int n_ctile = round_up(N, BW) / BW - ct0;
     const int n_ttile = (M + BT - 1) / BT;
     const int nblk = n_ctile * n_ttile;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI, BT>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * (TILE_BYTES + BT * 128));
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_ready{0};
+    if (!esmk_reserve_lds((const void*)gemm_kernel<EPI, BT>, 2 * (TILE_BYTES + BT * 128), lds_ready))
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", 2 * (TILE_BYTES + BT * 128));
     hipLaunchKernelGGL((gemm_kernel<EPI, BT>), dim3(nblk), dim3(256), 2 * (TILE_BYTES + BT * 128), s, (const __bf16*)A, lda,
                        (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk, ct0);
     ESMK_CHECK_LAUNCH("esmk_gemm");
@@ -245,12 +242,9 @@ int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, co
     const int n_ctile = round_up(N, BW) / BW;
     const int n_ttile = (M + 127) / 128;
     const int nblk = n_ctile * n_ttile;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<EPI_PARTIAL, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  4 * TILE_BYTES);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_ready{0};
+    if (!esmk_reserve_lds((const void*)gemm_kernel<EPI_PARTIAL, 128>, 4 * TILE_BYTES, lds_ready))
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", 4 * TILE_BYTES);
     // two stages, two workgroups per CU: measured faster than four stages at one workgroup per CU (ESM3 1 x 512:
     // 6.9 vs 8.0 ms per forward) - with one wave per SIMD nothing overlaps the LDS reads with the MFMAs
     hipLaunchKernelGGL((gemm_kernel<EPI_PARTIAL, 128>), dim3(nblk, S), dim3(256), 4 * TILE_BYTES, s, (const __bf16*)A, lda,

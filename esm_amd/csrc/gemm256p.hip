@@ -322,10 +322,10 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, float alp
             ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot query the device");
         ncu = prop.multiProcessorCount & ~7;  // multiple of 8 keeps a workgroup's tiles on one XCD
         if (ncu < 8) ncu = 8;
-        if (hipFuncSetAttribute((const void*)gemm256p_kernel<ESMK_EPI_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess ||
-            hipFuncSetAttribute((const void*)gemm256p_kernel<ESMK_EPI_SWIGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", LDS_BYTES);
     }
+    static std::atomic<unsigned long long> lds_ready{0};
+    if (!esmk_reserve_lds((const void*)gemm256p_kernel<EPI>, LDS_BYTES, lds_ready))
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", LDS_BYTES);
     const int grid = nblk < ncu ? nblk : ncu;
     hipLaunchKernelGGL(gemm256p_kernel<EPI>, dim3(grid), dim3(512), LDS_BYTES, s, (const __bf16*)A, lda,
                        (const __bf16*)W, Kpad, M, N, Kpad / BK, alpha, out, n_ctile, nblk, gt);

@@ -275,12 +275,9 @@ static int launch288(const void* A, int lda, const void* W, int M, int N, int K,
     const int nblk = n_ctile * n_ttile;
     static int gt = 0;
     if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void*)gemm288_kernel<NQM>, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS_BYTES) != hipSuccess)
-            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", C::LDS_BYTES);
-        attr_done = true;
-    }
+    static std::atomic<unsigned long long> lds_ready{0};
+    if (!esmk_reserve_lds((const void*)gemm288_kernel<NQM>, C::LDS_BYTES, lds_ready))
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(C::LDS_BYTES));
     hipLaunchKernelGGL(gemm288_kernel<NQM>, dim3(nblk), dim3(512), C::LDS_BYTES, s, (const __bf16*)A, lda, (const __bf16*)W,
                        Kpad, M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt);
     ESMK_CHECK_LAUNCH("esmk_gemm(288/192)");
