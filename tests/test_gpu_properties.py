@@ -86,3 +86,30 @@ def test_long_sequence_4096(model):
     # the first 64 residues must differ from a truncated run (they attend to the whole sequence)
     short = model(tok[:, :64], return_hidden_states=False)
     assert (out.embeddings[0, :64] - short.embeddings[0]).abs().max().item() > 1e-3
+
+
+def test_full_c2_config_rows_match_oracle():
+    """The bench workload itself (ESM C 600M-shaped, 36 layers, 64 x 512 residues in one forward): rows of the full
+    batch against the CPU oracle run on those rows alone - the north-star gate (per-residue cosine >= 0.999, logits
+    within 0.05 + 0.02 max|logit|) at BASELINE.json's full size, plus row-to-row independence inside the big batch."""
+    from esm_amd.esmc import ESMC
+    from oracle import trunk_ref  # checker only
+    d, H, NL = 1152, 18, 36
+    w = synth.esmc_weights(d, NL, seed=0)
+    m = ESMC(d, H, NL)
+    m.load_state_dict(w)
+    m = m.cuda()
+    tok = synth.synth_tokens([512] * 64, seed=1234)
+    out = m(tok.cuda(), return_hidden_states=False)
+    rows = [0, 37, 63]
+    ref = trunk_ref.esmc_forward(tok[rows], w, H, NL)
+    emb, lg = out.embeddings[rows].cpu(), out.sequence_logits[rows].cpu()
+    cos = torch.nn.functional.cosine_similarity(emb, ref["embeddings"], dim=-1).min().item()
+    err = (lg - ref["sequence_logits"]).abs().max().item()
+    lim = 0.05 + 0.02 * ref["sequence_logits"].abs().max().item()
+    assert cos >= 0.999, cos
+    assert err <= lim, (err, lim)
+    # the same three sequences as a batch of their own: every row depends on its own tokens only
+    small = m(tok[rows].cuda(), return_hidden_states=False)
+    c2 = torch.nn.functional.cosine_similarity(small.embeddings.cpu(), emb, dim=-1).min().item()
+    assert c2 >= 0.9999, c2
