@@ -374,15 +374,18 @@ class ESM3(nn.Module):
     # ---- ESMProtein <-> ESMProteinTensor for the sequence and structure tracks ----------------------
     @torch.no_grad()
     def encode(self, input: ESMProtein) -> ESMProteinTensor:
-        """esm3.py:414-493 for `sequence` and `coordinates` (secondary structure, SASA and function annotations need
-        the reference's other tokenizers and their data files: NotImplementedError).  coordinates [L, >=3, 3] with
+        """esm3.py:414-493 for `sequence`, `secondary_structure`, `sasa` and `coordinates` (function annotations need
+        the InterPro tokenizers' data files).  coordinates [L, >=3, 3] with
         N, CA, C first (atom37 works), NaN where unknown -> structure tokens from the VQ-VAE encoder, BOS / EOS added,
         coordinates padded with inf rows (utils/encoding.py:48-97)."""
-        from .tokenization import EsmSequenceTokenizer, tokenize_sequence
-        if input.secondary_structure is not None or input.sasa is not None:
-            raise NotImplementedError("only the sequence and structure tracks can be encoded here")
+        from .tokenization import (EsmSequenceTokenizer, SASADiscretizingTokenizer, SecondaryStructureTokenizer,
+                                   tokenize_sasa, tokenize_secondary_structure, tokenize_sequence)
         dev = self.device
-        seq_tok = struct_tok = coords = None
+        seq_tok = struct_tok = coords = ss_tok = sasa_tok = None
+        if input.secondary_structure is not None:
+            ss_tok = tokenize_secondary_structure(input.secondary_structure, SecondaryStructureTokenizer()).to(dev)
+        if input.sasa is not None:
+            sasa_tok = tokenize_sasa(input.sasa, SASADiscretizingTokenizer()).to(dev)
         if input.sequence is not None:
             tok = getattr(self.tokenizers, "sequence", None)
             if not hasattr(tok, "encode"):
@@ -398,22 +401,28 @@ class ESM3(nn.Module):
             struct_tok = torch.nn.functional.pad(t[0], (1, 1), value=STRUCTURE_MASK_TOKEN)
             struct_tok[0], struct_tok[-1] = STRUCTURE_BOS_TOKEN, STRUCTURE_EOS_TOKEN
             coords = torch.nn.functional.pad(c, (0, 0, 0, 0, 1, 1), value=torch.inf)
-        if seq_tok is None and struct_tok is None:
-            raise ValueError("Cannot infer input length from input data. Please provide one of: sequence, structure")
-        return ESMProteinTensor(sequence=seq_tok, structure=struct_tok, coordinates=coords,
-                                potential_sequence_of_concern=input.potential_sequence_of_concern)
+        if seq_tok is None and struct_tok is None and ss_tok is None and sasa_tok is None:
+            raise ValueError("Cannot infer input length from input data. Please provide one of: sequence, structure, "
+                             "secondary_structure, sasa.")
+        return ESMProteinTensor(sequence=seq_tok, structure=struct_tok, secondary_structure=ss_tok, sasa=sasa_tok,
+                                coordinates=coords, potential_sequence_of_concern=input.potential_sequence_of_concern)
 
     @torch.no_grad()
     def decode(self, input: ESMProteinTensor) -> ESMProtein:
-        """utils/decoding.py:28-111 for the sequence and structure tracks: the structure tokens (when none of them is
+        """utils/decoding.py:28-111 for the sequence, secondary-structure, SASA and structure tracks: the structure tokens (when none of them is
         MASK) go through the VQ-VAE decoder and take priority over `coordinates`.  coordinates come back as the
         backbone N, CA, C [L, 3, 3]: all-atom reconstruction (`ProteinChain.infer_oxygen`) is out of scope."""
-        from .tokenization import EsmSequenceTokenizer, decode_sequence
+        from .tokenization import (EsmSequenceTokenizer, SASADiscretizingTokenizer, SecondaryStructureTokenizer,
+                                   decode_sasa, decode_secondary_structure, decode_sequence)
         from .vqvae import decode_structure
-        if input.secondary_structure is not None or input.sasa is not None or input.function is not None or \
-                input.residue_annotations is not None:
-            raise NotImplementedError("only the sequence and structure tracks can be decoded here")
-        sequence = coords = plddt = ptm = pae = None
+        if input.function is not None or input.residue_annotations is not None:
+            raise NotImplementedError("function / residue annotations need the InterPro vocabularies (data files)")
+        sequence = coords = plddt = ptm = pae = secondary_structure = sasa = None
+        # a track whose body is all <pad> decodes to None (decoding.py:46-56)
+        if input.secondary_structure is not None and not bool((input.secondary_structure[1:-1] == 0).all()):
+            secondary_structure = decode_secondary_structure(input.secondary_structure.cpu(), SecondaryStructureTokenizer())
+        if input.sasa is not None and not bool((input.sasa[1:-1] == 0).all()):
+            sasa = decode_sasa(input.sasa.cpu(), SASADiscretizingTokenizer())
         if input.sequence is not None and not bool((input.sequence[1:-1] == SEQUENCE_PAD_TOKEN).all()):
             tok = getattr(self.tokenizers, "sequence", None)
             if not hasattr(tok, "decode"):
@@ -428,8 +437,8 @@ class ESM3(nn.Module):
             coords, plddt, ptm, pae = decode_structure(st.to(self.device), self.get_structure_decoder())
         elif input.coordinates is not None:
             coords = input.coordinates[1:-1, ...]
-        return ESMProtein(sequence=sequence, coordinates=coords, plddt=plddt, ptm=ptm, pae=pae,
-                          potential_sequence_of_concern=input.potential_sequence_of_concern)
+        return ESMProtein(sequence=sequence, secondary_structure=secondary_structure, sasa=sasa, coordinates=coords,
+                          plddt=plddt, ptm=ptm, pae=pae, potential_sequence_of_concern=input.potential_sequence_of_concern)
 
     def forward_and_sample(self, input: ESMProteinTensor, sampling_configuration, generator=None):
         """One forward + one sampling step per configured track (reference esm3.py:561-599 with

@@ -199,12 +199,12 @@ class _Tok:
 
 
 def default_track_tokenizers():
-    from .tokenization import EsmSequenceTokenizer
+    from .tokenization import EsmSequenceTokenizer, SASADiscretizingTokenizer, SecondaryStructureTokenizer
     return {
         "sequence": EsmSequenceTokenizer(),
         "structure": _Tok(4096, 4101, [4096, 4097, 4098, 4099, 4100]),   # structure_tokenizer.py:10-17
-        "secondary_structure": _Tok(0, 11, [0, 1, 2]),                     # ss_tokenizer.py:18-33 (<pad> doubles as mask)
-        "sasa": _Tok(0, 19, [0, 1, 2]),                                    # sasa_tokenizer.py (same convention)
+        "secondary_structure": SecondaryStructureTokenizer(),              # 11 ids, <pad> doubles as mask
+        "sasa": SASADiscretizingTokenizer(),                               # 19 ids, same convention
     }
 
 

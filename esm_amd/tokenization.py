@@ -131,6 +131,118 @@ def decode_sequence(sequence_tokens, sequence_tokenizer: EsmSequenceTokenizer) -
     return s.replace(sequence_tokenizer.cls_token, "").replace(sequence_tokenizer.eos_token, "")
 
 
+# ---- secondary-structure and SASA tracks (no data files needed: esm/tokenization/ss_tokenizer.py,
+#      sasa_tokenizer.py; esm/utils/encoding.py:100-135, decoding.py:172-203) --------------------------------------
+SSE_8CLASS_VOCAB = "GHITEBSC"   # esm/utils/constants/esm3.py
+SSE_3CLASS_VOCAB = "HEC"
+SASA_DISCRETIZATION_BOUNDARIES = [0.8, 4.0, 9.6, 16.4, 24.5, 32.9, 42.0, 51.5, 61.2, 70.9, 81.6, 93.3, 107.2, 125.4, 151.4]
+
+
+class _PadIsEverything:
+    """Both tokenizers use <pad> (id 0) as mask, BOS, EOS, pad and chain break (ss_tokenizer.py:79-117)."""
+    special_tokens = ["<pad>", "<motif>", "<unk>"]
+    mask_token = bos_token = eos_token = pad_token = chain_break_token = "<pad>"
+    mask_token_id = bos_token_id = eos_token_id = pad_token_id = chain_break_token_id = 0
+
+    @property
+    def vocab_to_index(self) -> dict:
+        return {w: i for i, w in enumerate(self.vocab)}
+
+    @property
+    def all_token_ids(self):
+        return list(range(len(self.vocab)))
+
+    @property
+    def special_token_ids(self):
+        return [0, 1, 2]
+
+    def get_special_tokens_mask(self, tokens: torch.Tensor) -> torch.Tensor:
+        return tokens < len(self.special_tokens)
+
+
+class SecondaryStructureTokenizer(_PadIsEverything):
+    def __init__(self, kind: str = "ss8"):
+        assert kind in ("ss8", "ss3")
+        self.kind = kind
+        self.vocab = [*self.special_tokens, *(SSE_8CLASS_VOCAB if kind == "ss8" else SSE_3CLASS_VOCAB)]
+
+    def encode(self, sequence, add_special_tokens: bool = True) -> torch.Tensor:
+        v = self.vocab_to_index
+        ids = [v[ch] for ch in sequence]  # KeyError on an unknown symbol, like the reference
+        if add_special_tokens:
+            ids = [0, *ids, 0]
+        return torch.tensor(ids, dtype=torch.int64)
+
+    def decode(self, encoded: torch.Tensor) -> str:
+        return "".join(self.vocab[int(i)] for i in encoded)
+
+
+class SASADiscretizingTokenizer(_PadIsEverything):
+    def __init__(self, boundaries=SASA_DISCRETIZATION_BOUNDARIES):
+        self._boundaries = sorted(boundaries)
+        b = ["0"] + [str(x) for x in self._boundaries] + ["inf"]
+        self.vocab = self.special_tokens + [f"<{lo}-{hi}>" for lo, hi in zip(b[:-1], b[1:])]
+        e = [0] + self._boundaries + [self._boundaries[-1] * 2]
+        self.midpoints_tensor = torch.Tensor([float("nan")] * 3 + [(float(hi) + float(lo)) / 2 for lo, hi in zip(e[:-1], e[1:])])
+
+    def midpoints(self) -> list:
+        return self.midpoints_tensor.tolist()
+
+    def encode(self, values, add_special_tokens: bool = True) -> torch.Tensor:
+        v, bnd, ids = self.vocab_to_index, torch.tensor(self._boundaries), []
+        for value in values:
+            if isinstance(value, (float, int)):
+                ids.append(3 + int(torch.bucketize(torch.tensor(float(value)), bnd)))
+            elif isinstance(value, str):
+                ids.append(v[value])
+            else:
+                raise TypeError(value)
+        if add_special_tokens:
+            ids = [0, *ids, 0]
+        return torch.tensor(ids, dtype=torch.int64)
+
+    def decode_float(self, encoded: torch.Tensor) -> list:
+        # special tokens decode to NaN (the reference assigns None into a float array, which stores NaN)
+        return self.midpoints_tensor[encoded.cpu()].tolist()
+
+    def decode_list(self, encoded: torch.Tensor) -> list:
+        return [self.vocab[int(i)] for i in encoded]
+
+    def decode(self, encoded: torch.Tensor) -> str:
+        return ",".join(self.decode_list(encoded))
+
+
+def tokenize_secondary_structure(secondary_structure, tokenizer: SecondaryStructureTokenizer,
+                                 add_special_tokens: bool = True) -> torch.Tensor:
+    """encoding.py:100-123: one symbol per residue, '_' (or the tokenizer's own mask string) = masked."""
+    if isinstance(secondary_structure, str):
+        secondary_structure = secondary_structure.replace(tokenizer.mask_token, MASK_STR_SHORT)
+    chars = [tokenizer.mask_token if ch == MASK_STR_SHORT else ch for ch in secondary_structure]
+    return tokenizer.encode(chars, add_special_tokens=add_special_tokens)
+
+
+def tokenize_sasa(sasa, tokenizer: SASADiscretizingTokenizer, add_special_tokens: bool = True) -> torch.Tensor:
+    """encoding.py:126-135: None = masked."""
+    return tokenizer.encode([tokenizer.mask_token if v is None else v for v in sasa], add_special_tokens=add_special_tokens)
+
+
+def decode_secondary_structure(tokens: torch.Tensor, tokenizer: SecondaryStructureTokenizer) -> str:
+    return tokenizer.decode(tokens[1:-1])  # decoding.py:172-178
+
+
+def decode_sasa(tokens: torch.Tensor, tokenizer: SASADiscretizingTokenizer) -> list:
+    """decoding.py:181-203: integer tokens -> bin mid-points (NaN for special tokens); float values (what
+    forward_and_sample returns for this track) pass through with NaN -> None."""
+    if tokens[0] != 0:
+        raise ValueError("SASA does not start with 0 corresponding to BOS token")
+    if tokens[-1] != 0:
+        raise ValueError("SASA does not end with 0 corresponding to EOS token")
+    body = tokens[1:-1]
+    if body.dtype in (torch.int8, torch.int16, torch.int32, torch.int64):
+        return tokenizer.decode_float(body)
+    return [None if x != x else x for x in body.tolist()]
+
+
 def stack_variable_length_tensors(sequences: Sequence[torch.Tensor], constant_value=0, dtype=None) -> torch.Tensor:
     """Right-pad to a common shape (reference esm/utils/misc.py:177-206)."""
     shape = [len(sequences)] + np.max([list(s.shape) for s in sequences], 0).tolist()

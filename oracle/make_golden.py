@@ -294,8 +294,23 @@ def text_cases():
     attrs["chain_break_token_id"] = tok.convert_tokens_to_ids("|")
     attrs["all_token_ids"] = list(tok.all_token_ids)
     attrs["special_token_ids"] = sorted(tok.special_token_ids)
+    # secondary-structure and SASA tokenizers (ss_tokenizer.py, sasa_tokenizer.py, encoding.py:100-135)
+    from esm.tokenization.sasa_tokenizer import SASADiscretizingTokenizer
+    from esm.tokenization.ss_tokenizer import SecondaryStructureTokenizer
+    ss_tok, sasa_tok = SecondaryStructureTokenizer(), SASADiscretizingTokenizer()
+    ss_cases = []
+    for text in ("GHITEBSC", "CC_HH__EE", "", "<pad>HH<pad>E", "_"):
+        ids = encoding.tokenize_secondary_structure(text, ss_tok)
+        ss_cases.append({"text": text, "ids": ids.tolist(), "decoded": ss_tok.decode(ids[1:-1])})
+    sasa_cases = []
+    for vals in ([0.0, 0.8, 0.81, 3.99, 4.0, 150.0, 151.4, 151.5, 1e6], [None, 12.5, "<unk>", 33, None], [], [None]):
+        ids = encoding.tokenize_sasa(vals, sasa_tok)
+        sasa_cases.append({"values": vals, "ids": ids.tolist(), "decode_float": sasa_tok.decode_float(ids[1:-1]),
+                           "decode": sasa_tok.decode(ids[1:-1])})
+    extra = {"ss8": ss_cases, "ss8_vocab": ss_tok.vocab, "ss3_vocab": SecondaryStructureTokenizer("ss3").vocab,
+             "sasa": sasa_cases, "sasa_vocab": sasa_tok.vocab, "sasa_midpoints": [None if m != m else m for m in sasa_tok.midpoints()]}
     with open(os.path.join(OUT, "text_inputs.json"), "w") as f:
-        json.dump({"tokenizer": cases, "tokenizer_attrs": attrs, "fasta_text": FASTA_TEXT, "fasta_entries": fasta}, f, indent=1)
+        json.dump({"tokenizer": cases, "tokenizer_attrs": attrs, "fasta_text": FASTA_TEXT, "fasta_entries": fasta, **extra}, f, indent=1)
     print("text_inputs.json written")
 
 

@@ -59,8 +59,24 @@ def test_encode_forward_decode():
         model.encode(ESMProtein(sequence=seq[:-1], coordinates=coords))
     with pytest.raises(ValueError):
         model.encode(ESMProtein())
-    with pytest.raises(NotImplementedError):
-        model.encode(ESMProtein(sequence=seq, secondary_structure="C" * Ln))
+    # secondary-structure and SASA tracks: encode -> logits conditioned on them -> decode back
+    ss = ("HHHHEEEE__CC" * Ln)[:Ln]
+    sasa = [None if i % 5 == 0 else 7.5 * (i % 23) for i in range(Ln)]
+    pt2 = model.encode(ESMProtein(sequence=seq, secondary_structure=ss, sasa=sasa))
+    assert pt2.secondary_structure.shape == (Ln + 2,) and pt2.sasa.shape == (Ln + 2,) and pt2.sasa.is_cuda
+    assert pt2.secondary_structure[0] == 0 and pt2.secondary_structure[-1] == 0 and int(pt2.secondary_structure.max()) <= 10
+    lo = model.logits(pt2, LogitsConfig(sequence=True, secondary_structure=True, sasa=True))
+    base = model.logits(ESMProteinTensor(sequence=pt2.sequence), LogitsConfig(sequence=True))
+    assert torch.isfinite(lo.logits.sasa).all() and lo.logits.secondary_structure.shape[-1] == 11
+    assert (lo.logits.sequence - base.logits.sequence).abs().max().item() > 1e-3   # the extra tracks do condition the model
+    back = model.decode(pt2)
+    assert back.sequence == seq
+    assert back.secondary_structure == ss.replace("_", "<pad>")
+    assert len(back.sasa) == Ln and all((a is None) == (b != b) for a, b in zip(sasa, back.sasa))
+    # a track that is all <pad> decodes to None (decoding.py:46-56)
+    empty = model.decode(ESMProteinTensor(sequence=pt2.sequence, sasa=torch.zeros(Ln + 2, dtype=torch.long)))
+    assert empty.sasa is None
+    assert len(model.encode(ESMProtein(secondary_structure="HHEE"))) == 6   # length inferred from the track alone
 
 
 def test_missing_builders_raise():

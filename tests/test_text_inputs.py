@@ -97,3 +97,38 @@ def test_save_load_embeddings(tmp_path):
     assert load_embeddings(tmp_path / "h.safetensors")[1].dtype == torch.bfloat16
     with pytest.raises(ValueError):
         save_embeddings(tmp_path / "bad.safetensors", ["only one"], emb)
+
+
+def test_ss8_and_sasa_tokenizers_match_reference():
+    """SecondaryStructureTokenizer / SASADiscretizingTokenizer + tokenize_* / decode_* against the outputs of the
+    reference's own classes (ss_tokenizer.py, sasa_tokenizer.py, encoding.py:100-135)."""
+    import math
+
+    from esm_amd.tokenization import (SASADiscretizingTokenizer, SecondaryStructureTokenizer, decode_sasa,
+                                      decode_secondary_structure, tokenize_sasa, tokenize_secondary_structure)
+    ss, sasa = SecondaryStructureTokenizer(), SASADiscretizingTokenizer()
+    assert ss.vocab == GOLD["ss8_vocab"] and SecondaryStructureTokenizer("ss3").vocab == GOLD["ss3_vocab"]
+    assert sasa.vocab == GOLD["sasa_vocab"]
+    same = lambda a, b: (a is None and b is None) or (isinstance(a, float) and isinstance(b, float) and
+                                                     ((math.isnan(a) and math.isnan(b)) or abs(a - b) < 1e-6))
+    mids = [None if m != m else m for m in sasa.midpoints()]
+    assert len(mids) == len(GOLD["sasa_midpoints"]) and all(same(a, b) for a, b in zip(mids, GOLD["sasa_midpoints"]))
+    for c in GOLD["ss8"]:
+        ids = tokenize_secondary_structure(c["text"], ss)
+        assert ids.tolist() == c["ids"], c["text"]
+        assert decode_secondary_structure(ids, ss) == c["decoded"]
+    for c in GOLD["sasa"]:
+        ids = tokenize_sasa(c["values"], sasa)
+        assert ids.tolist() == c["ids"], c["values"]
+        got = sasa.decode_float(ids[1:-1])
+        assert len(got) == len(c["decode_float"]) and all(same(float(a), float(b)) for a, b in zip(got, c["decode_float"]))
+        assert sasa.decode(ids[1:-1]) == c["decode"]
+        assert len(decode_sasa(ids, sasa)) == len(c["values"])
+    with pytest.raises(KeyError):
+        ss.encode("GXH")
+    with pytest.raises(ValueError):
+        decode_sasa(torch.tensor([3, 4, 0]), sasa)
+    assert decode_sasa(torch.tensor([0.0, 1.5, float("nan"), 0.0]), sasa) == [1.5, None]
+    for t in (ss, sasa):
+        assert t.mask_token_id == t.pad_token_id == t.bos_token_id == t.eos_token_id == 0 and t.special_token_ids == [0, 1, 2]
+    assert len(ss.all_token_ids) == 11 and len(sasa.all_token_ids) == 19
