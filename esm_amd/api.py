@@ -87,6 +87,22 @@ class _BatchedESMProteinTensor(ESMProteinTensor):
     def batch_size(self) -> int:
         return next(iter({v.size(0) for v in self._tensors().values()}))
 
+    def slice(self, i: int, sequence_len: int | None = None) -> ESMProteinTensor:
+        """Row i as an ESMProteinTensor, optionally trimmed to its true length (sampling.py:76-93)."""
+        cut = lambda x: None if x is None else (x[i] if sequence_len is None else x[i][:sequence_len])
+        return ESMProteinTensor(**{f.name: cut(getattr(self, f.name)) for f in fields(ESMProteinTensor)
+                                   if f.name != "potential_sequence_of_concern"})
+
+    def set_slice(self, i: int, slice: ESMProteinTensor):
+        """Write `slice` into row i, track by track (sampling.py:95-106)."""
+        for f in fields(ESMProteinTensor):
+            if f.name == "potential_sequence_of_concern":
+                continue
+            s, v = getattr(self, f.name), getattr(slice, f.name)
+            assert v is None or s is not None, f"Trying to set a slice on None tensor ({f.name})."
+            if v is not None:
+                s[i, ...] = v
+
 
 @dataclass
 class ESMProteinError(Exception):

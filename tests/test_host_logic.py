@@ -142,3 +142,16 @@ def test_block_variants_state_dict_and_rejections():
         TransformerStack(128, 2, None, 1, n_layers_geom=0, ffn_type="relu")
     with pytest.raises(ValueError):
         TransformerStack(128, 2, None, 1, n_layers_geom=1)  # v_heads missing
+
+
+def test_batched_protein_tensor_slice_roundtrip():
+    from esm_amd.api import ESMProteinTensor, _BatchedESMProteinTensor
+    b = _BatchedESMProteinTensor(sequence=torch.arange(12).view(2, 6), coordinates=torch.zeros(2, 6, 3, 3))
+    assert len(b) == 6 and b.batch_size == 2
+    r = b.slice(1, sequence_len=4)
+    assert isinstance(r, ESMProteinTensor) and r.sequence.tolist() == [6, 7, 8, 9] and r.coordinates.shape == (4, 3, 3)
+    assert r.structure is None
+    b.set_slice(0, ESMProteinTensor(sequence=torch.full((6,), 9)))
+    assert b.sequence[0].tolist() == [9] * 6 and b.sequence[1].tolist() == [6, 7, 8, 9, 10, 11]
+    with pytest.raises(AssertionError):
+        b.set_slice(0, ESMProteinTensor(structure=torch.zeros(6, dtype=torch.long)))
