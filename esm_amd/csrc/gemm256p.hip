@@ -25,7 +25,8 @@ constexpr int TB = 256;
 constexpr int BK = 64;
 constexpr int UNIT = 128 * 128;
 constexpr int KBUF = 4 * UNIT;
-constexpr int LDS_BYTES = 2 * KBUF;
+constexpr int STAGE_BYTES = 32 * 1024;            // SwiGLU epilogue staging: 4 KiB per wave, beside the K-tile ring
+constexpr int LDS_BYTES = 2 * KBUF + STAGE_BYTES;  // 160 KiB = all of a CU's LDS
 
 #define SEG_BARRIER()                        \
     do {                                     \
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
                                                           int nt, float alpha, void* __restrict__ out,
                                                           int n_ctile, int nblk, int gt) {
     static_assert(EPI == ESMK_EPI_BF16 || EPI == ESMK_EPI_SWIGLU, "persistent kernel: bf16 / SwiGLU epilogues only");
-    constexpr int NS = (EPI == ESMK_EPI_SWIGLU) ? 16 : 32;  // epilogue stores per wave
+    constexpr int NS = (EPI == ESMK_EPI_SWIGLU) ? 8 : 32;  // epilogue stores per wave
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -78,24 +79,22 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         t0 = (panel * gt + (idp - ctile * gtp)) * TB;
     };
 
-    // DMA sources.  Wave w moves pieces 2w, 2w+1 (8 rows x 128 B) of every unit.  To keep the VGPR budget
-    // (128 accumulators + 64 fragment registers at 2 waves/SIMD) the per-lane offsets are recomputed at every
-    // issue from the lane id; only wave-uniform tile state (bases, row limit) is carried across K-tiles.
+    // DMA sources.  Wave w moves pieces 2w, 2w+1 (8 rows x 128 B) of every unit, in the buffer form of the LDS-DMA
+    // (as gemm256.hip): tile base in a scalar descriptor, per-lane 32-bit offset, and the K offset plus the unit's
+    // wave-uniform row step (unit 3: +64 W rows, unit 2: +32 A rows) in the scalar offset - four offset registers,
+    // no per-piece 64-bit vector arithmetic, no branches.  Only wave-uniform tile state (the two bases) is carried
+    // across K-tiles.  Token tiles are always full: esmk_gemm256p takes M % 256 == 0 only.
     struct Src {
         const char* wbase;
         const char* abase;
-        int lim;  // last valid token row relative to the tile's first row
     };
     auto make_src = [&](int c0, int t0) {
         Src s;
         s.wbase = (const char*)(W + (size_t)c0 * ldw);
         s.abase = (const char*)(A + (size_t)t0 * lda);
-        s.lim = M - 1 - t0;
         return s;
     };
     const int dma_dst = wave * 2048;
-    // four precomputed per-lane byte offsets (piece 0 / 1 of a W unit and of an A unit); unit 3 / unit 2 add a
-    // wave-uniform 64-row / 32-row step.  Ragged token tiles (row clamp needed) take the slow recompute path.
     unsigned offW[2], offA[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -107,19 +106,11 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
     // stream position g -> LDS buffer g&1;  (src, kt) name the tile and K offset of that position
     auto issue_piece = [&](int u, int i, int g, const Src& s, int kt) {
         char* dst = smem + (g & 1) * KBUF + u * UNIT + dma_dst + i * 1024;
-        const size_t koff = (size_t)kt * (BK * 2);
-        const char* p;
-        if (u == 0 || u == 3) {
-            p = s.wbase + koff + (u == 3 ? (size_t)64 * ldw * 2 : 0) + offW[i];
-        } else if (s.lim >= 255) {
-            p = s.abase + koff + (u == 2 ? (size_t)32 * lda * 2 : 0) + offA[i];
-        } else {  // ragged last token tile: clamp the row
-            const int r = wave * 16 + i * 8 + (lane >> 3);
-            const unsigned lc = (unsigned)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
-            const int row = min((r >> 5) * 64 + (r & 31) + (u == 2 ? 32 : 0), s.lim);
-            p = s.abase + koff + ((unsigned)row * (unsigned)(lda * 2) + lc);
-        }
-        __builtin_amdgcn_global_load_lds(GLB_PTR(p), LDS_PTR(dst), 16, 0, 0);
+        const bool w = (u == 0 || u == 3);
+        const int sof = kt * (BK * 2) + (u == 3 ? 64 * ldw * 2 : (u == 2 ? 32 * lda * 2 : 0));
+        const __amdgpu_buffer_rsrc_t r =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(w ? s.wbase : s.abase), 0, 0x7fffffff, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(dst), 16, (int)(w ? offW[i] : offA[i]), sof, 0, 0);
     };
 
     const int ra = wm * 64 + (lane & 15), rb = wn * 32 + (lane & 15);
@@ -156,6 +147,42 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         __builtin_amdgcn_make_buffer_rsrc(out, 0, (int)((size_t)M * OW * 2), 0x00020000);
     auto epilogue = [&](int c0, int t0) {
         const int q4 = (lane >> 4) * 4;
+        if constexpr (EPI == ESMK_EPI_SWIGLU) {
+            // The wave's 64 tokens x 64 output channels go out as whole 128-byte rows: two passes of 32 tokens through
+            // the wave's own 4 KiB of LDS BESIDE the K-tile ring (which already holds the next tile's operands).
+            // Image: 32 rows x 128 B, 16-byte chunk XOR-swizzled by (row>>1)&7 (conflict-free 8-byte writes of 16 rows
+            // x 32 B and 16-byte row reads).  DS operations of one wave execute in order: no waits between the passes.
+            char* stg = smem + 2 * KBUF + wave * 4096;
+            const int rrow = lane >> 3, rchunk = lane & 7;  // read side: 8 rows x 8 chunks per instruction
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn) {
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int r = ni * 16 + (lane & 15);
+#pragma unroll
+                    for (int qm = 0; qm < 2; ++qm)
+#pragma unroll
+                        for (int mi = 0; mi < 4; mi += 2) {
+                            const f32x4 g = acc[qm][qn][mi][ni], u = acc[qm][qn][mi + 1][ni];
+                            u32x2 v;
+                            v.x = pack_bf16x2(silu(g[0]) * u[0], silu(g[1]) * u[1]);
+                            v.y = pack_bf16x2(silu(g[2]) * u[2], silu(g[3]) * u[3]);
+                            const int cl = qm * 32 + (mi >> 1) * 16 + q4;  // channel inside the wave's 64
+                            *(u32x2*)(stg + r * 128 + ((((cl >> 3) ^ (r >> 1)) & 7) << 4) + (cl & 4) * 2) = v;
+                        }
+                }
+                const int cc = ((c0 + wm * 128) >> 1) + rchunk * 8;
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int r = it * 8 + rrow;
+                    const u32x4 v = *(const u32x4*)(stg + r * 128 + (((rchunk ^ (r >> 1)) & 7) << 4));
+                    const int t = t0 + wn * 64 + qn * 32 + r;
+                    const unsigned off = (t < M && cc < OW) ? (unsigned)t * (unsigned)(OW * 2) + (unsigned)cc * 2u : 0x80000000u;
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (int)off, 0, 0);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int qn = 0; qn < 2; ++qn)
 #pragma unroll
@@ -269,8 +296,8 @@ __global__ __launch_bounds__(512, 2) void gemm256p_kernel(const __bf16* __restri
         const int k2 = in_cur ? kt + 2 : kt + 2 - nt;
         const int late = stored ? kt : 2;  // 0 / 1: the previous tile's stores are still ahead of the group we need
         KTILE(true, true,
-              { if (late < 2) { if constexpr (NS == 16) WAITV(24); else WAITV(40); } else WAITV(8); },
-              { if (late < 1) { if constexpr (NS == 16) WAITV(24); else WAITV(40); } else WAITV(8); })
+              { if (late < 2) { if constexpr (NS == 8) WAITV(16); else WAITV(40); } else WAITV(8); },
+              { if (late < 1) { if constexpr (NS == 8) WAITV(16); else WAITV(40); } else WAITV(8); })
         if (kt == 0) PSTAMP(3 * (g / nt));
         if (++kt == nt) {  // tile finished: flush it, move on (its successor's first two K-tiles are in flight)
             PSTAMP(3 * (g / nt) + 1);
@@ -335,11 +362,14 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, float alp
 
 }  // namespace
 
-// Persistent path: bf16 / SwiGLU epilogues, K >= 128, output < 2 GiB.  Returns 1 when the shape is not eligible.
+// Persistent path: bf16 / SwiGLU epilogues, K >= 128, M a multiple of 256, output < 2 GiB.  Returns 1 when the shape
+// is not eligible.
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s) {
     const int OW = (epilogue == ESMK_EPI_SWIGLU) ? N / 2 : N;
     if (round_up(K, BK) / BK < 2 || (OW & 3) || (size_t)M * OW * 2 >= 0x7fffffffull) return 1;
+    if (epilogue == ESMK_EPI_SWIGLU && (OW & 7)) return 1;  // staged epilogue stores 16-byte pieces of whole rows
+    if (M % TB) return 1;                                   // full token tiles only (no row clamp in the DMA offsets)
     if (epilogue == ESMK_EPI_BF16) return launch<ESMK_EPI_BF16>(A, lda, W, M, N, K, alpha, out, s);
     if (epilogue == ESMK_EPI_SWIGLU) return launch<ESMK_EPI_SWIGLU>(A, lda, W, M, N, K, alpha, out, s);
     return 1;
