@@ -290,7 +290,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r] + (c + r < N ? bias[c + r] : 0.f));
                             } else {
-                                v *= alpha;
+                                v = scale4(v, alpha);
                             }
                             u32x2 pk;
                             pk.x = pack_bf16x2(v[0], v[1]);

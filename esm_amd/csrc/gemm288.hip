@@ -223,7 +223,7 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
                 const int trow = qn * 32 + ni * 16 + (lane & 15);
 #pragma unroll
                 for (int mi = 0; mi < 3; ++mi) {
-                    const f32x4 v = acc[qm][qn][mi][ni] * alpha;
+                    const f32x4 v = scale4(acc[qm][qn][mi][ni], alpha);
                     u32x2 pk;
                     pk.x = pack_bf16x2(v[0], v[1]);
                     pk.y = pack_bf16x2(v[2], v[3]);

@@ -44,7 +44,7 @@ __device__ __forceinline__ void epi_store4(f32x4 v, int t, int c, int N, const f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] += (c + r < N ? bias[c + r] : 0.f);
             }
-            v *= alpha;
+            v = scale4(v, alpha);
         }
         if (full) {
             u32x2 pk;
