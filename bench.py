@@ -38,8 +38,8 @@ PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
 DOMINANT_KERNEL_HBM_BYTES = 880_983_979
 # Fraction of cycles the MFMA pipes are busy during that kernel, at the clock the chip held (rocprofv3 --pmc
 # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) over this very bench: tools/pmc_mfma_util.py,
-# profiles/r01_pmc_mfma_util.json; whole run incl. weight packing: 0.425)
-DOMINANT_KERNEL_MFMA_BUSY = 0.5914
+# profiles/r01_pmc_mfma_util.json; whole run incl. weight packing: 0.434)
+DOMINANT_KERNEL_MFMA_BUSY = 0.5993
 
 
 def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
