@@ -9,6 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libesmk.so")
+# experiments build (make EXPERIMENTS=1): alternative GEMM kernels + ESMK_GEMM_* switches; tools/ and tests only
+XLIB_PATH = os.path.join(_HERE, "libesmk_x.so")
 
 F32, BF16 = 0, 1
 PACK_PLAIN, PACK_SWIGLU = 0, 1
@@ -50,6 +52,7 @@ class EsmkHead(C.Structure):
 SIGNATURES = {
     "esmk_version": (C.c_int, []),
     "esmk_last_error": (C.c_char_p, []),
+    "esmk_build_id": (C.c_char_p, []),
     "esmk_packed_weight_bytes": (C.c_size_t, [C.c_int, C.c_int]),
     "esmk_pack_weight": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_layernorm": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, vp]),
@@ -93,25 +96,39 @@ class EsmkError(RuntimeError):
 
 
 _lib = None
+_xlib = None
+
+
+def _load(path):
+    if not os.path.exists(path):
+        raise EsmkError(f"{path} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(or `make -C esm_amd/csrc`). There is no non-HIP fallback.")
+    # torch ships its own libamdhip64 (same soname): load it FIRST so that libesmk.so binds to the one HIP
+    # runtime torch's allocator and streams live in; the other order leaves two runtimes in the process.
+    import torch  # noqa: F401
+    l = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args
+    return l
 
 
 def lib():
     """Load libesmk.so; raises (never falls back) when it is missing."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise EsmkError(f"{LIB_PATH} not found - build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                            "(or `make -C esm_amd/csrc`). There is no non-HIP fallback.")
-        # torch ships its own libamdhip64 (same soname): load it FIRST so that libesmk.so binds to the one HIP
-        # runtime torch's allocator and streams live in; the other order leaves two runtimes in the process.
-        import torch  # noqa: F401
-        l = C.CDLL(LIB_PATH)
-        for name, (res, args) in SIGNATURES.items():
-            fn = getattr(l, name)
-            fn.restype = res
-            fn.argtypes = args
-        _lib = l
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def lib_experiments():
+    """libesmk_x.so: same C-ABI, built with -DESMK_EXPERIMENTS (alternative GEMM kernels selected by ESMK_GEMM_*
+    environment variables).  For tools/ and tests; the product package never calls this."""
+    global _xlib
+    if _xlib is None:
+        _xlib = _load(XLIB_PATH)
+    return _xlib
 
 
 def check(rc: int, what: str = ""):

@@ -33,6 +33,19 @@ void esmk_set_error(const char* fmt, ...);
 
 static inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
 
+// Experiment switches.  The product library (libesmk.so) compiles every switch to its default: one dispatch path,
+// no environment lookups.  Only the experiments build (`make EXPERIMENTS=1` -> libesmk_x.so, used by tools/ and by the
+// tests that cover the alternative kernels) reads them from the environment, per call.
+#ifdef ESMK_EXPERIMENTS
+#include <stdlib.h>
+static inline int esmk_switch(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+static inline constexpr int esmk_switch(const char*, int dflt) { return dflt; }
+#endif
+
 // Kernels that need more than 64 KiB of dynamic LDS must be told so once PER DEVICE (the attribute belongs to the
 // device's copy of the code object).  `done` is a per-kernel bit mask of devices already set up; a lost race between
 // threads only repeats the (idempotent) call.  Returns false when the runtime refuses.

@@ -11,8 +11,6 @@
 // chunk index is XOR-swizzled with (row>>1)&7 - applied on the per-lane SOURCE address (the DMA writes
 // LDS linearly) and on the ds_read_b128 address - which makes the 16-lane ds_read_b128 groups
 // conflict-free.
-#include <stdlib.h>
-
 #include "common.hpp"
 #include "gemm_epi.hpp"
 
@@ -262,34 +260,30 @@ int launch_splitk(const void* A, int lda, const void* W, int M, int N, int K, co
 
 int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                  float alpha, void* out, hipStream_t s, int n_ctile);
+int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
+int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
+
+#ifdef ESMK_EXPERIMENTS
+// Alternative kernels of the experiments build only (libesmk_x.so): the four-wave 128x128-wave-tile kernels
+// (gemm4w.hip: LDS-DMA operands, ESMK_GEMM_4W=1; gemm4v.hip: operands staged through VGPRs, ESMK_GEMM_4W=2) and the
+// persistent cross-tile-prefetch kernel (gemm256p.hip, ESMK_GEMM_PERSIST=1).  All measured slower than the product
+// kernels; kept for A/B runs and covered by tests/test_gpu_kernels.py through libesmk_x.so.
 int esmk_gemm4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                 float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm4v(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                 float alpha, void* out, hipStream_t s, int n_ctile);
-int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
-int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm256p(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, float alpha, void* out,
                   hipStream_t s);
+#endif
 
-// ESMK_GEMM_4W=1: the four-wave 128x128-wave-tile kernel (gemm4w.hip) takes the place of the eight-wave 256-tile
-// kernel (A/B experiments; read per call so that tests can exercise both)
-static int gemm256_or_4w(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
-                         float alpha, void* out, hipStream_t s, int n_ctile) {
-    const char* e = getenv("ESMK_GEMM_4W");
-    const int v = e ? atoi(e) : 0;
-    if (v == 2) return esmk_gemm4v(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);  // VGPR-staged operands
+static int gemm256_tile(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
+                        float alpha, void* out, hipStream_t s, int n_ctile) {
+#ifdef ESMK_EXPERIMENTS
+    const int v = esmk_switch("ESMK_GEMM_4W", 0);
+    if (v == 2) return esmk_gemm4v(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
     if (v) return esmk_gemm4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
+#endif
     return esmk_gemm256(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, n_ctile);
-}
-
-// 0 = auto, 128 / 256 = force a tile family (ESMK_GEMM_TILE environment variable; for experiments and tests)
-static int gemm_tile_override() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("ESMK_GEMM_TILE");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
 }
 
 extern "C" size_t esmk_packed_weight_bytes(int N, int K) {
@@ -336,7 +330,7 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
     if (epilogue == ESMK_EPI_BIAS_GELU && !bias) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: bias+gelu epilogue needs a bias");
     {
         // large problems: 256x256 ping-pong kernel; small / skinny ones: 128x128 (more, smaller workgroups)
-        const int ov = gemm_tile_override();
+        const int ov = esmk_switch("ESMK_GEMM_TILE", 0);  // experiments: 128 / 256 force a tile family
         // measured crossover (tools/gemm_bench.py, M = 512 ... 32768): the 256-tile kernel wins once there are
         // about half as many 256x256 tiles as CUs; below that the 128-tile kernel fills the chip better.
         // a bias with the bf16 epilogue (bias=True block variants) is applied by the 128-tile kernel and the split-K
@@ -344,10 +338,8 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         const bool bias128 = bias && epilogue == ESMK_EPI_BF16;
         const bool big = !bias128 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
         // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
-        static int use288 = -1;
-        if (use288 < 0) { const char* e5 = getenv("ESMK_GEMM_288"); use288 = e5 ? atoi(e5) : 1; }
-        static int force192 = -1;  // ESMK_GEMM_192=1: prefer 192-channel tiles wherever N % 192 == 0 (experiments)
-        if (force192 < 0) { const char* e6 = getenv("ESMK_GEMM_192"); force192 = e6 ? atoi(e6) : 0; }
+        const int use288 = esmk_switch("ESMK_GEMM_288", 1);
+        const int force192 = esmk_switch("ESMK_GEMM_192", 0);  // prefer 192-channel tiles wherever N % 192 == 0
         if (force192 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 192) == 0 && (long long)((M + 255) / 256) * (N / 192) >= 128)
             return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
         if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
@@ -362,27 +354,24 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
             if (nt * (N / 192) >= 128 && c192 < c256) return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
         }
         if ((ov == 256 && !bias128) || (ov == 0 && big)) {
-            // ESMK_GEMM_PERSIST=1 selects the persistent cross-tile-prefetch kernel (gemm256p.hip).  Default off:
-            // measured equal (FFN up-projection) or slower (QKV) than the dispatch-staggered kernel.  Read per call
-            // so that tests can exercise both.
-            const char* e = getenv("ESMK_GEMM_PERSIST");
-            const int persist = e ? atoi(e) : 0;
+            const int persist = esmk_switch("ESMK_GEMM_PERSIST", 0);
+#ifdef ESMK_EXPERIMENTS
             if (persist && (epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU)) {
                 const int rc = esmk_gemm256p(A, lda, W, M, N, K, epilogue, alpha, out, s);
                 if (rc <= 0) return rc;  // 1 = shape not eligible for the persistent kernel
             }
+#endif
             // Split dispatch: when the last 256-channel tile column is at most half full (N = 1152: 4.5 columns)
             // and dropping it saves a whole round of workgroups over the 256 CUs (640 -> 512 tiles: 3 -> 2
             // rounds), the 256-kernel covers the full columns and the 128-tile kernel the remaining <= 128
             // channels; its small workgroups start as soon as CUs drain from the last full round.
             const int nt = (M + 255) / 256, nc = (N + 255) / 256;
             const int rem = N - (nc - 1) * 256;
-            static int split_on = -1;
-            if (split_on < 0) { const char* e2 = getenv("ESMK_GEMM_SPLIT"); split_on = e2 ? atoi(e2) : 1; }
+            const int split_on = esmk_switch("ESMK_GEMM_SPLIT", 1);
             const bool split = split_on && !persist && nc >= 2 && rem <= 128 && epilogue != ESMK_EPI_SWIGLU &&
                                (nt * (nc - 1) + 255) / 256 < (nt * nc + 255) / 256;
-            if (!split) return gemm256_or_4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc);
-            const int rc = gemm256_or_4w(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc - 1);
+            if (!split) return gemm256_tile(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc);
+            const int rc = gemm256_tile(A, lda, W, M, N, K, epilogue, bias, alpha, out, s, nc - 1);
             if (rc != ESMK_OK) return rc;
             const int ct0 = (nc - 1) * 2;
             switch (epilogue) {
@@ -396,9 +385,8 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
     }
     // small problems: split K over several workgroups per tile when the caller lent a workspace for the partials
     // (not for the read-modify-write residual epilogue: its output is also an input)
-    static int splitk_on = -1;
-    if (splitk_on < 0) { const char* e3 = getenv("ESMK_GEMM_SPLITK"); splitk_on = e3 ? atoi(e3) : 1; }
-    const int S = (splitk_on && workspace && epilogue != ESMK_EPI_RESIDUAL && gemm_tile_override() == 0) ? splitk_factor(M, N, K) : 1;
+    const int splitk_on = esmk_switch("ESMK_GEMM_SPLITK", 1);
+    const int S = (splitk_on && workspace && epilogue != ESMK_EPI_RESIDUAL && esmk_switch("ESMK_GEMM_TILE", 0) == 0) ? splitk_factor(M, N, K) : 1;
     if (S > 1 && workspace_bytes >= esmk_gemm_workspace_bytes(M, N, K) && !((uintptr_t)workspace & 15)) {
         float* part = (float*)workspace;
         switch (epilogue) {

@@ -342,8 +342,8 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, const flo
     const int Kpad = round_up(K, BK);
     const int n_ttile = (M + TB - 1) / TB;
     const int nblk = n_ctile * n_ttile;
-    static int gt = 0;
-    if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
+    int gt = esmk_switch("ESMK_GEMM_GT", 4);  // panel width of the tile order (4: best or within noise on every shape)
+    if (gt < 1) gt = 1;
     static std::atomic<unsigned long long> lds_ready{0};
     if (!esmk_reserve_lds((const void*)gemm256_kernel<EPI>, LDS_BYTES, lds_ready))
         ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(LDS_BYTES));

@@ -340,8 +340,7 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, float alp
     const int nblk = n_ctile * n_ttile;
     static int gt = 0, ncu = 0;
     if (gt == 0) {
-        const char* e = getenv("ESMK_GEMM_GT");
-        gt = e ? atoi(e) : 4;
+        gt = esmk_switch("ESMK_GEMM_GT", 4);
         if (gt < 1) gt = 1;
         int dev = 0;
         hipDeviceProp_t prop;

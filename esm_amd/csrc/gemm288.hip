@@ -273,8 +273,8 @@ static int launch288(const void* A, int lda, const void* W, int M, int N, int K,
     const int n_ctile = N / C::TC;
     const int n_ttile = (M + TT - 1) / TT;
     const int nblk = n_ctile * n_ttile;
-    static int gt = 0;
-    if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
+    int gt = esmk_switch("ESMK_GEMM_GT", 4);  // panel width of the tile order (4: best or within noise on every shape)
+    if (gt < 1) gt = 1;
     static std::atomic<unsigned long long> lds_ready{0};
     if (!esmk_reserve_lds((const void*)gemm288_kernel<NQM>, C::LDS_BYTES, lds_ready))
         ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(C::LDS_BYTES));

@@ -291,7 +291,7 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, const flo
     const int n_ttile = (M + TB - 1) / TB;
     const int nblk = n_ctile * n_ttile;
     static int gt = 0;
-    if (gt == 0) { const char* e = getenv("ESMK_GEMM_GT"); gt = e ? atoi(e) : 4; if (gt < 1) gt = 1; }
+    if (gt == 0) { gt = esmk_switch("ESMK_GEMM_GT", 4); if (gt < 1) gt = 1; }
     static std::atomic<unsigned long long> lds_ready{0};
     if (!esmk_reserve_lds((const void*)gemm4v_kernel<EPI>, LDS_BYTES, lds_ready))
         ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(LDS_BYTES));

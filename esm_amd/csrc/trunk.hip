@@ -1,10 +1,11 @@
 // Host-side driver: the whole TransformerStack forward (and the RegressionHead) as one C call that only
-// enqueues kernels on the caller's stream.  No allocation, no synchronisation, no global mutable state
-// besides the thread-local error string.
+// enqueues kernels on the caller's stream.  No allocation, no synchronisation; process-wide state is the
+// thread-local error string and what include/esmk.h lists under "Conventions".
 #include <math.h>
 #include <stdarg.h>
 #include <string.h>
 
+#include "build_id.h"
 #include "common.hpp"
 
 static thread_local char g_err[512] = "";
@@ -20,6 +21,13 @@ void esmk_set_error(const char* fmt, ...) {
 
 extern "C" int esmk_version(void) { return ESMK_VERSION; }
 extern "C" const char* esmk_last_error(void) { return g_err; }
+extern "C" const char* esmk_build_id(void) {
+#ifdef ESMK_EXPERIMENTS
+    return ESMK_BUILD_ID "+x";
+#else
+    return ESMK_BUILD_ID;
+#endif
+}
 
 namespace {
 

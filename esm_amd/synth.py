@@ -232,6 +232,12 @@ def esm3_weights(d: int, n_layers: int, v_heads: int, seed: int = 0) -> dict:
 # --------------------------------------------------------------------------------------
 # synthetic inputs (SURVEY.md section 8d / BASELINE.md section 3)
 # --------------------------------------------------------------------------------------
+def synth_activations(shape, seed: int, std: float = 1.0) -> torch.Tensor:
+    """N(0, std) activations from the same Philox stream as the weights: large test inputs are regenerated from
+    their seed on the GPU box instead of being stored in a fixture."""
+    return _draw("activations", shape, seed, 0.0, std)
+
+
 def synth_tokens(lengths, pad_to: int | None = None, seed: int = 1234) -> torch.Tensor:
     """[B, Lmax] int64: <cls> + residues(4..23) + <eos>, right-padded with <pad>=1."""
     lengths = [int(x) for x in lengths]

@@ -11,8 +11,13 @@
  *   - plain C: raw DEVICE pointers, explicit sizes, a HIP stream passed as void*; no torch types.
  *   - every function returns 0 on success, <0 on error (ESMK_ERR_*); esmk_last_error() gives text.
  *     Nothing throws, aborts or exits.  Shapes are validated on the host before any launch.
- *   - the caller owns every buffer; nothing here allocates device memory or synchronises the device.
+ *   - the caller owns every buffer; nothing here allocates device memory or synchronises the device
+ *     (exception, named where it is declared: esmk_event_elapsed_ms waits for its event).
  *   - work is enqueued on `stream` and is ordered with other work on that stream.
+ *   - process-wide state: a thread-local error string; per kernel a bit mask of the devices on which its
+ *     dynamic-LDS limit has been raised (set once, idempotent).  No environment variable is read by this library (the ESMK_GEMM_* switches exist only in the
+ *     separate experiments build, libesmk_x.so).  Entry points are re-entrant across threads and streams unless
+ *     their comment says otherwise.
  *   - activations: packed tokens, row-major [n_tokens, width]; no row padding is required.
  *   - "packed weight": bf16 [round_up(N,256), round_up(K,64)] produced by esmk_pack_weight.
  */
@@ -26,7 +31,7 @@
 extern "C" {
 #endif
 
-#define ESMK_VERSION 100
+#define ESMK_VERSION 200
 
 #define ESMK_OK 0
 #define ESMK_ERR_INVALID_ARG (-1)
@@ -42,6 +47,9 @@ typedef void* esmk_stream_t; /* hipStream_t */
 
 int esmk_version(void);
 const char* esmk_last_error(void);
+/* 12 hex digits: hash of the sources this binary was built from (written by the Makefile).  bench.py and the
+ * profiles under profiles/ carry it, so a measured number can be tied to one binary.  No reference counterpart. */
+const char* esmk_build_id(void);
 
 /* ------------------------------------------------------------------------------------------
  * Weight packing (once per model).

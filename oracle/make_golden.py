@@ -90,6 +90,31 @@ def stack_case(name, d, H, NL, L, wseed, scale_residue=True):
          post=_np(post[:, ::4]), pre=_np(pre[:, ::4]), token_stride=4, scale_residue=int(scale_residue))
 
 
+def stack_long_case(name, d, H, NL, L, wseed, row_stride, n_pad=100):
+    """True-width trunk at a long sequence (config C5: d2560 / 40 heads at L = 4096): one row, the last n_pad positions
+    masked out.  The input is regenerated from its seed by the test (synth.synth_activations), outputs are stored
+    for every row_stride-th position."""
+    w = synth.make_weights(synth.trunk_shapes("", d, NL), seed=wseed)
+    m = ref_import.build_stack(d, H, NL, w)
+    x = synth.synth_activations((1, L, d), seed=wseed + 17)
+    sid = torch.ones(1, L, dtype=torch.bool)
+    sid[0, L - n_pad:] = False
+    with torch.no_grad():
+        post, pre, hid = m(x, sequence_id=sid)
+    save(name, kind="stack", d=d, H=H, NL=NL, wseed=wseed, x_seed=wseed + 17, x_shape=np.asarray([1, L, d]),
+         sequence_id=_np(sid), post=_np(post[:, ::row_stride]), pre=_np(pre[:, ::row_stride]), token_stride=row_stride,
+         scale_residue=1)
+
+
+def fullsize_cases():
+    """BASELINE.json configs C3 and C5 at their full sequence lengths (round 2): the 256-head geometric attention on
+    512-key rows, the ESM3-open-shaped model at full depth on one 512-residue protein, and the d2560 trunk at L = 4096."""
+    geom_case("geom_d1536_vh256_L512", 1536, 256, 1, 512, wseed=44, variant="multichain", nan_frac=0.1, row_stride=8)
+    stack_long_case("stack_d2560_L4096", 2560, 40, 2, 4096, wseed=71, row_stride=64)
+    esm3_case("esm3_open_48l_L512", 1536, 24, 256, 48, 1, 512, [512], wseed=54, iseed=504, with_tracks=False,
+              big_stride=32, emb_stride=8)
+
+
 def stack_variant_case(name, d, H, NL, L, wseed, VH=None, **kw):
     """TransformerStack with the other block variants of blocks.py:73-115 (bias / no QK-LayerNorm / GELU FFN /
     geometric attention without frameless zeroing): input activations (+ coordinates, chains) -> (post, pre).
@@ -194,7 +219,8 @@ def esm3_inputs(B, L, lengths, seed, with_tracks=True):
     return kw
 
 
-def esm3_case(name, d, H, VH, NL, B, L, lengths, wseed, iseed, extra=None, with_tracks=True, big_stride=1):
+def esm3_case(name, d, H, VH, NL, B, L, lengths, wseed, iseed, extra=None, with_tracks=True, big_stride=1,
+              emb_stride=1):
     w = synth.esm3_weights(d, NL, VH, seed=wseed)
     m = ref_import.build_esm3(d, H, VH, NL, w)
     kw = esm3_inputs(B, L, lengths, iseed, with_tracks)
@@ -202,18 +228,21 @@ def esm3_case(name, d, H, VH, NL, B, L, lengths, wseed, iseed, extra=None, with_
         kw.update(extra)
     with torch.no_grad():
         out = m(**kw)
-    arrays = dict(kind="esm3", d=d, H=H, VH=VH, NL=NL, wseed=wseed, big_stride=big_stride)
+    arrays = dict(kind="esm3", d=d, H=H, VH=VH, NL=NL, wseed=wseed, big_stride=big_stride, emb_stride=emb_stride)
     for k, v in kw.items():
         arrays["in_" + k] = _np(v)
-    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits", "embeddings"):
+    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits"):
         arrays[k] = _np(getattr(out, k))
+    arrays["embeddings"] = _np(out.embeddings[:, ::emb_stride])
     for k in ("structure_logits", "function_logits", "residue_logits"):
         arrays[k] = _np(getattr(out, k)[:, ::big_stride])
     save(name, **arrays)
 
 
-def geom_case(name, d, VH, B, L, wseed, variant):
-    """GeometricReasoningOriginalImpl alone (block 0 of a 1-layer geom stack shares the weights)."""
+def geom_case(name, d, VH, B, L, wseed, variant, nan_frac=0.2, row_stride=1):
+    """GeometricReasoningOriginalImpl alone (block 0 of a 1-layer geom stack shares the weights).  row_stride > 1:
+    the input s is NOT stored (the test regenerates it with synth.synth_activations(seed = wseed + 3)) and only every
+    row_stride-th output row is."""
     ref_import.install()
     from esm.layers.geom_attention import GeometricReasoningOriginalImpl
     from esm.utils.structure.affine3d import build_affine3d_from_coordinates
@@ -223,9 +252,12 @@ def geom_case(name, d, VH, B, L, wseed, variant):
     w = synth.make_weights({"blocks.0.geom_attn." + k: v for k, v in shapes.items()}, seed=wseed)
     mod = GeometricReasoningOriginalImpl(c_s=d, v_heads=VH, mask_and_zero_frameless=True).eval()
     mod.load_state_dict({k[len("blocks.0.geom_attn."):]: v for k, v in w.items()}, strict=True)
-    g = torch.Generator().manual_seed(wseed + 3)
-    s = torch.randn(B, L, d, generator=g)
-    coords = synth.synth_backbone(B, L, seed=wseed + 4, nan_frac=0.2)
+    if row_stride > 1:
+        s = synth.synth_activations((B, L, d), seed=wseed + 3)
+    else:
+        g = torch.Generator().manual_seed(wseed + 3)
+        s = torch.randn(B, L, d, generator=g)
+    coords = synth.synth_backbone(B, L, seed=wseed + 4, nan_frac=nan_frac)
     sid = None
     chain = torch.zeros(B, L, dtype=torch.int64)
     if variant == "nostruct":
@@ -241,8 +273,12 @@ def geom_case(name, d, VH, B, L, wseed, variant):
     affine, mask = build_affine3d_from_coordinates(coords)
     with torch.no_grad():
         out = mod(s, affine, mask, sid, chain)
-    arrays = dict(kind="geom", d=d, VH=VH, wseed=wseed, s=_np(s), coords=_np(coords), chain_id=_np(chain),
-                  out=_np(out), affine=_np(affine.tensor), affine_mask=_np(mask))
+    arrays = dict(kind="geom", d=d, VH=VH, wseed=wseed, coords=_np(coords), chain_id=_np(chain),
+                  out=_np(out[:, ::row_stride]), affine=_np(affine.tensor), affine_mask=_np(mask), row_stride=row_stride)
+    if row_stride > 1:
+        arrays.update(s_seed=wseed + 3, s_shape=np.asarray([B, L, d]))
+    else:
+        arrays["s"] = _np(s)
     if sid is not None:
         arrays["sequence_id"] = _np(sid)
     save(name, **arrays)
@@ -518,6 +554,8 @@ def main():
         return fdec_cases()
     if "--stack-variants-only" in sys.argv:
         return stack_variant_cases()
+    if "--fullsize-only" in sys.argv:
+        return fullsize_cases()
     text_cases()
     sampling_cases()
     # (i) tiny ESMC under the three sequence_id dialects
@@ -577,6 +615,8 @@ def main():
     fdec_cases()
     # (x) the remaining block variants through the generic TransformerStack
     stack_variant_cases()
+    # (xi) configs C3 / C5 at full sequence length
+    fullsize_cases()
 
 
 if __name__ == "__main__":

@@ -18,6 +18,13 @@ def t(a):
     return torch.from_numpy(np.ascontiguousarray(a))
 
 
+def seeded(fx, key):
+    """Input tensor `key` of a fixture: stored, or (large inputs) regenerated from the seed the fixture names."""
+    if key in fx:
+        return t(fx[key])
+    return synth.synth_activations(tuple(int(v) for v in fx[key + "_shape"]), seed=int(fx[key + "_seed"]))
+
+
 def esm3_kwargs(fx):
     return {k[3:]: t(v) for k, v in fx.items() if k.startswith("in_")}
 

@@ -24,13 +24,28 @@ def test_header_symbols_exported():
         assert hasattr(lib, n), f"{n} declared in esmk.h but not exported by libesmk.so"
 
 
+def test_only_header_symbols_exported_and_no_env_switches():
+    """The product library exports exactly the header's entry points and reads no environment variable; the
+    experiments library exports the same ABI."""
+    import subprocess
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        return {l.split()[-1] for l in out.splitlines() if l.strip()}
+    names = declared_functions()
+    assert exported(_lib.LIB_PATH) == names
+    und = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    assert "getenv" not in und
+    assert exported(_lib.XLIB_PATH) == names
+
+
 def test_ctypes_table_matches_header():
     assert set(_lib.SIGNATURES) == declared_functions()
 
 
 def test_version_and_host_only_calls():
     lib = _lib.lib()
-    assert lib.esmk_version() == 100
+    assert lib.esmk_version() == 200
+    assert re.fullmatch(rb"[0-9a-f]{12}", lib.esmk_build_id())
     assert lib.esmk_packed_weight_bytes(3456, 1152) == 3584 * 1152 * 2  # rows padded to 256
     assert lib.esmk_packed_weight_bytes(11, 24) == 256 * 64 * 2
     assert lib.esmk_head_workspace_bytes(100, 128) >= 3 * 100 * 128 * 2

@@ -50,6 +50,8 @@ def test_gemm_many_tiles(M, N, K, swiglu, persist, fourw, monkeypatch):
     monkeypatch.setenv("ESMK_GEMM_PERSIST", persist)
     monkeypatch.setenv("ESMK_GEMM_4W", fourw)
     L, lib, engine = _env()
+    if (persist, fourw) != ("0", "0"):
+        lib = L.lib_experiments()  # the alternative kernels live in libesmk_x.so only; the product library has no switches
     g = torch.Generator().manual_seed(M + N)
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
     W = torch.randn(N, K, generator=g) * 0.05
@@ -76,6 +78,8 @@ def test_gemm_256_tile_other_epilogues(M, N, K, fourw, monkeypatch):
     them (>= 128 tiles), ragged M and a ragged channel column included; one K-tile and three."""
     monkeypatch.setenv("ESMK_GEMM_4W", fourw)
     L, lib, engine = _env()
+    if fourw != "0":
+        lib = L.lib_experiments()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
     W = torch.randn(N, K, generator=g) * 0.1

@@ -128,7 +128,7 @@ def test_esm3_vs_golden(name):
 
 
 @pytest.mark.parametrize("name", ["geom_plain", "geom_nostruct", "geom_multichain", "geom_binpacked",
-                                  "geom_onerow_frameless", "geom_d1536_vh256"])
+                                  "geom_onerow_frameless", "geom_d1536_vh256", "geom_d1536_vh256_L512"])
 def test_geom_core_vs_golden(name):
     """esmk_geom_attn alone: proj (fp32, computed here from the fixture's s) -> pre-out_proj 3-vectors."""
     import numpy as np
@@ -138,7 +138,7 @@ def test_geom_core_vs_golden(name):
     w = G.weights_for(fx)
     p = "blocks.0.geom_attn."
     VH, d = int(fx["VH"]), int(fx["d"])
-    s = G.t(fx["s"])
+    s = G.seeded(fx, "s")  # the L = 512 case (config C3: 256 heads on 512-key rows) regenerates s from its seed
     B, Ln, _ = s.shape
     M = B * Ln
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else torch.zeros(B, Ln, dtype=torch.int64)
@@ -163,8 +163,9 @@ def test_geom_core_vs_golden(name):
     got = out.float().cpu()
     assert torch.isfinite(got).all()
     assert got[:, 3 * VH:].abs().max().item() == 0.0 if ld > 3 * VH else True
-    full = got[:, :3 * VH] @ w[p + "out_proj.weight"].T
-    ref = G.t(fx["out"]).reshape(M, d)
+    rs = int(fx["row_stride"]) if "row_stride" in fx else 1
+    full = (got[:, :3 * VH] @ w[p + "out_proj.weight"].T).reshape(B, Ln, d)[:, ::rs].reshape(-1, d)
+    ref = G.t(fx["out"]).reshape(-1, d)
     assert (full - ref).abs().max().item() <= 0.02 * max(ref.abs().max().item(), 1e-3) + 1e-4
     if name == "geom_nostruct":
         assert got.abs().max().item() == 0.0

@@ -30,12 +30,13 @@ def test_esmc(name):
     _close(out["hidden_states"][hl][:, :, ::s][:, valid], G.t(fx["hidden_states"])[:, valid])
 
 
-@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560", "stack_d1280_vqdec"])
+@pytest.mark.parametrize("name", ["stack_tiny_nomask", "stack_d960", "stack_d1152", "stack_d1536", "stack_d2560", "stack_d1280_vqdec",
+                                  "stack_d2560_L4096"])
 def test_stack(name):
     fx = G.load(name)
     w = G.weights_for(fx)
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
-    post, pre, _ = trunk_ref.transformer_stack(G.t(fx["x"]), sid, w, "", int(fx["H"]), int(fx["NL"]),
+    post, pre, _ = trunk_ref.transformer_stack(G.seeded(fx, "x"), sid, w, "", int(fx["H"]), int(fx["NL"]),
                                                scale_residue=bool(int(fx["scale_residue"])) if "scale_residue" in fx else True)
     s = int(fx["token_stride"])
     valid = sid[:, ::s] if sid is not None else torch.ones(post[:, ::s].shape[:2], dtype=torch.bool)
@@ -77,30 +78,34 @@ def test_frames():
 
 
 @pytest.mark.parametrize("name", ["geom_plain", "geom_nostruct", "geom_multichain", "geom_binpacked",
-                                  "geom_onerow_frameless", "geom_d1536_vh256"])
+                                  "geom_onerow_frameless", "geom_d1536_vh256", "geom_d1536_vh256_L512"])
 def test_geom(name):
     fx = G.load(name)
     w = G.weights_for(fx)
     rot, trans, mask = trunk_ref.build_frames(G.t(fx["coords"]))
     sid = G.t(fx["sequence_id"]) if "sequence_id" in fx else None
-    out = trunk_ref.geometric_attention(G.t(fx["s"]), rot, trans, mask, sid, G.t(fx["chain_id"]), w,
+    out = trunk_ref.geometric_attention(G.seeded(fx, "s"), rot, trans, mask, sid, G.t(fx["chain_id"]), w,
                                         "blocks.0.geom_attn.", int(fx["VH"]))
-    _close(out, G.t(fx["out"]))
+    rs = int(fx["row_stride"]) if "row_stride" in fx else 1
+    _close(out[:, ::rs], G.t(fx["out"]))
     if name == "geom_nostruct":
         assert out.abs().max().item() == 0.0
 
 
 @pytest.mark.parametrize("name", ["esm3_tiny_alltracks", "esm3_tiny_seqstruct", "esm3_tiny_chain_seqid",
-                                  "esm3_d1536_2layer"])
+                                  "esm3_d1536_2layer", "esm3_open_48l_L512"])
 def test_esm3(name):
     fx = G.load(name)
     w = G.weights_for(fx)
     out = trunk_ref.esm3_forward(w, int(fx["H"]), int(fx["VH"]), int(fx["NL"]), **G.esm3_kwargs(fx))
     bs = int(fx["big_stride"])
-    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits", "embeddings"):
-        _close(out[k], G.t(fx[k]))
+    es = int(fx["emb_stride"]) if "emb_stride" in fx else 1
+    tol = 2e-4 if int(fx["NL"]) >= 30 else None  # fp32 summation-order drift over 48 layers
+    for k in ("sequence_logits", "secondary_structure_logits", "sasa_logits"):
+        _close(out[k], G.t(fx[k]), *([tol] if tol else []))
+    _close(out["embeddings"][:, ::es], G.t(fx["embeddings"]), *([tol] if tol else []))
     for k in ("structure_logits", "function_logits", "residue_logits"):
-        _close(out[k][:, ::bs], G.t(fx[k]))
+        _close(out[k][:, ::bs], G.t(fx[k]), *([tol] if tol else []))
 
 
 VQDEC_KEYS = ("tensor7_affine", "bb_pred", "plddt", "ptm", "predicted_aligned_error")
