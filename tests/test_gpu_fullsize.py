@@ -124,7 +124,7 @@ def test_c5_80_layers_4x4096_properties():
     post_b, pre_b, _ = eng.forward(x0.clone(), batch, want_post=True, want_hiddens=False)
     torch.cuda.synchronize()
     assert torch.isfinite(post_a).all() and torch.isfinite(pre_a).all()
-    assert post_a.std(dim=-1).min().item() > 0.1
+    assert pre_a.std(dim=-1).min().item() > 0.1  # rows of the residual stream are not degenerate
     assert torch.equal(post_a, post_b) and torch.equal(pre_a, pre_b)
     # row 2 alone: another batch shape (other GEMM tile schedule, same arithmetic up to fp32 summation order)
     one = DeviceBatch(pack_lengths([L]), "cuda")
