@@ -61,6 +61,7 @@ SIGNATURES = {
     "esmk_gemm": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_gemm_workspace_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "esmk_gemm_ws": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_size_t, vp]),
+    "esmk_gemm_noalloc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),
     "esmk_attn_varlen": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),

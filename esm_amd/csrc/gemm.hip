@@ -315,6 +315,49 @@ extern "C" int esmk_gemm(const void* A, int lda, const void* W, int M, int N, in
     return esmk_gemm_ws(A, lda, W, M, N, K, epilogue, bias, alpha, out, nullptr, 0, stream);
 }
 
+// ---- allocation-free form (esmk_gemm_noalloc) -------------------------------------------------------------------
+// The split-K partials live in a device array that belongs to the library instead of a caller's workspace, for
+// callers that cannot allocate (HIP graph capture, serving loops).  `scratch` below is only the HOST-side handle of
+// that array: its device address differs per GPU and comes from hipGetSymbolAddress, once per device.
+constexpr size_t NOALLOC_SCRATCH_BYTES = (size_t)ESMK_GEMM_NOALLOC_MAX_BYTES;
+static __device__ __align__(256) unsigned char scratch[NOALLOC_SCRATCH_BYTES];
+static void* g_scratch_ptr[64];                                // device address of `scratch` on device i
+static std::atomic<unsigned long long> g_scratch_known{0};     // bit i: g_scratch_ptr[i] is valid
+
+static int noalloc_scratch_ptr(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm_noalloc: cannot identify the current device (index %d)", dev);
+    const unsigned long long bit = 1ull << dev;
+    if (!(g_scratch_known.load(std::memory_order_acquire) & bit)) {
+        void* p = nullptr;  // a lost race between two threads stores the same address twice
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p)
+            ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+        g_scratch_ptr[dev] = p;
+        g_scratch_known.fetch_or(bit, std::memory_order_release);
+    }
+    *out = g_scratch_ptr[dev];
+    return ESMK_OK;
+}
+
+extern "C" int esmk_gemm_noalloc(const void* A, int lda, const void* W, int M, int N, int K, int epilogue,
+                                 const float* bias, float alpha, void* out, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (M < 0 || N <= 0 || K <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm_noalloc: bad shape M=%d N=%d K=%d", M, N, K);
+    const size_t need = esmk_gemm_workspace_bytes(M, N, K);  // 0: the shape is not split, no scratch is touched
+    if (need > NOALLOC_SCRATCH_BYTES)
+        ESMK_FAIL(ESMK_ERR_WORKSPACE, "esmk_gemm_noalloc: M=%d N=%d K=%d needs %zu bytes of split-K partials, the library's "
+                  "fixed array holds %zu - use esmk_gemm_ws with a workspace of your own", M, N, K, need, NOALLOC_SCRATCH_BYTES);
+    void* part = nullptr;
+    if (need) {
+        const int rc = noalloc_scratch_ptr(&part);
+        if (rc != ESMK_OK) return rc;
+    }
+    // every partial the reduce pass reads is written by the first pass of the same call: nothing needs clearing
+    return esmk_gemm_ws(A, lda, W, M, N, K, epilogue, bias, alpha, out, part, need, stream);
+}
+
 extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
                             float alpha, void* out, void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;

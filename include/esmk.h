@@ -12,10 +12,12 @@
  *   - every function returns 0 on success, <0 on error (ESMK_ERR_*); esmk_last_error() gives text.
  *     Nothing throws, aborts or exits.  Shapes are validated on the host before any launch.
  *   - the caller owns every buffer; nothing here allocates device memory or synchronises the device
- *     (exception, named where it is declared: esmk_event_elapsed_ms waits for its event).
+ *     (exceptions, both named where they are declared: esmk_event_elapsed_ms waits for its event, and
+ *     esmk_gemm_noalloc uses a fixed device array that belongs to the library).
  *   - work is enqueued on `stream` and is ordered with other work on that stream.
  *   - process-wide state: a thread-local error string; per kernel a bit mask of the devices on which its
- *     dynamic-LDS limit has been raised (set once, idempotent).  No environment variable is read by this library (the ESMK_GEMM_* switches exist only in the
+ *     dynamic-LDS limit has been raised (set once, idempotent); the per-device address of the esmk_gemm_noalloc
+ *     array.  No environment variable is read by this library (the ESMK_GEMM_* switches exist only in the
  *     separate experiments build, libesmk_x.so).  Entry points are re-entrant across threads and streams unless
  *     their comment says otherwise.
  *   - activations: packed tokens, row-major [n_tokens, width]; no row padding is required.
@@ -116,6 +118,22 @@ size_t esmk_gemm_workspace_bytes(int M, int N, int K);
 int esmk_gemm_ws(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
                  const float* bias, float alpha, void* out, void* workspace, size_t workspace_bytes,
                  esmk_stream_t stream);
+
+/* Allocation-free form of esmk_gemm_ws.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory around the call - code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  Same operation, same kernels and bit-identical results as esmk_gemm_ws with a workspace of
+ * esmk_gemm_workspace_bytes(M, N, K) bytes, but the split-K partials live in a fixed device array of
+ * ESMK_GEMM_NOALLOC_MAX_BYTES that the library holds on every GPU it runs on until the process ends.
+ *   - a shape whose partials exceed the array is rejected with ESMK_ERR_WORKSPACE (with today's split rule no
+ *     shape needs more than 25.2 MB); a shape that is not split (esmk_gemm_workspace_bytes == 0) runs as esmk_gemm.
+ *   - calls no hipMalloc / hipFree and no allocating library routine; the first call on a device looks up the
+ *     array's address (hipGetSymbolAddress) - make one call per device before capturing a graph.
+ *   - all calls on one GPU share that GPU's array: two calls that overlap in time on one GPU (different streams or
+ *     threads) race on the partials.  Calls on one stream, or ordered by events, are safe.  Nothing is carried
+ *     between calls (every partial read is written first by the same call). */
+#define ESMK_GEMM_NOALLOC_MAX_BYTES (32u << 20)
+int esmk_gemm_noalloc(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
+                      const float* bias, float alpha, void* out, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * QK-LayerNorm + rotary, in place on the packed qkv buffer.
