@@ -1,18 +1,30 @@
-"""Headline benchmark: residues/sec of the ESM C 600M forward at L=512 (BASELINE.json config C2).
+"""Headline benchmark: residues/sec of the ESM C 600M forward (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`)
+    python bench.py --gpus N --steps K --warmup W [--config c2|c4]
 
-A step = one forward (embedding gather -> 36-block trunk -> sequence head) of one packed batch of
-64 x 512 synthetic residues per GPU, inputs resident in HBM.  Weak scaling: every rank runs its own batch
-with replicated weights and no data-path collective; the only collective is the result gather of the
-data-parallel runner (bf16 per-residue embeddings, on a side stream, overlapped with the next step).
-Rank 0 prints ONE JSON line.
+N > 1 without WORLD_SIZE in the environment: this process only LAUNCHES - it starts N workers (one per GPU, plain child
+processes, before anything here touches the GPU), waits for them and exits with the worst of their codes.  Under
+`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` the workers are the launcher's.
+
+--config c2 (default; BASELINE.json configs[1], the configuration the metric is quoted on)
+    A step = one forward (embedding gather -> 36-block trunk -> sequence head) of one packed batch of 64 x 512
+    synthetic residues per GPU, inputs resident in HBM.  Weak scaling: every rank runs its own batch with replicated
+    weights and no data-path collective; the only collective is the result gather (bf16 per-residue embeddings,
+    all_gather over RCCL on a side stream, overlapped with the next step).
+--config c4 (BASELINE.json configs[3])
+    A step = one pass over 4096 synthetic sequences with lengths log-uniform in [64, 2048] (seed 7), length-bucketed
+    into packs of <= 32768 tokens and sharded over the ranks by esm_amd.dp (longest-processing-time-first on the FLOP
+    model); per-residue bf16 embeddings are gathered to every rank round by round while the next pack computes
+    (dp.run_data_parallel, streaming form).  Strong scaling: the job is fixed, ranks split it.
+
+With more than one rank the gather is part of the step and MUST run over RCCL: a failing `nccl` initialisation or
+pre-flight gather ends the run with a non-zero exit code and the reason (no silent fallback).  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
-  roofline      dominant kernel = the FFN up-projection GEMM with the SwiGLU epilogue
-                (32768 x 6144 x 1152): algorithmic FLOPs / mean launch time from HIP events on the launch stream,
-                against the 2.5 PFLOP/s dense bf16 MFMA peak (MI355X_MICROARCH.md).
+  roofline      dominant kernel = the FFN up-projection GEMM with the SwiGLU epilogue: algorithmic FLOPs / mean launch
+                time from HIP events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak
+                (MI355X_MICROARCH.md).  `traffic` (HBM-side bytes per launch) is read from the PMC profile
+                profiles/r02_pmc_bench.json when that profile was taken with THIS binary (esmk_build_id), else null.
   cpu_baseline  the CPU oracle (fp32 restatement of the reference, oracle/trunk_ref.py) timed on this host's
                 cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -21,6 +33,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,18 +42,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 D_MODEL, N_HEADS, N_LAYERS, FFN_H = 1152, 18, 36, 3072
 BATCH, SEQ_LEN = 64, 512
 PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
-# HBM-side bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 [gfx950 correction for
-# 16-B/lane streams] + WRITE_SIZE, KiB -> bytes): profiles/r01_pmc_gemm_ffn1.json.  Algorithmic bytes: 291 MB.
-DOMINANT_KERNEL_HBM_BYTES = 880_983_979
-# Fraction of cycles the MFMA pipes are busy during that kernel, at the clock the chip held (rocprofv3 --pmc
-# SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs) over this very bench: tools/pmc_mfma_util.py,
-# profiles/r01_pmc_mfma_util.json; whole run incl. weight packing: 0.434)
-DOMINANT_KERNEL_MFMA_BUSY = 0.5993
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+C4_SEQS, C4_LMIN, C4_LMAX, C4_SEED, C4_BUDGET = 4096, 64, 2048, 7, 32768
 
 
 def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
@@ -47,6 +54,45 @@ def flop_per_residue(d=D_MODEL, h=FFN_H, L=SEQ_LEN, layers=N_LAYERS):
     return layers * (8 * d * d + 6 * d * h + 4 * L * d) + 2 * d * d + 2 * d * 64
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: runs in a process that never initialises the GPU
+# ------------------------------------------------------------------------------------------------------------------
+def self_launch(n: int) -> int:
+    """Start n workers of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) and wait."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ESM_AMD_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # RCCL across processes needs dmabuf IPC on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    worst = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                pending.remove(p)
+                if rc != 0:
+                    worst = worst or rc
+                    for q in pending:  # one worker failed: the others would wait in a collective forever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return worst
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# measurement helpers (worker side)
+# ------------------------------------------------------------------------------------------------------------------
 def time_dominant_kernel(model, tokens, batch, steps=3):
     """Mean in-situ launch duration (s) of the FFN up-projection (SwiGLU) GEMM: HIP events recorded on the
     launch stream around that kernel in every layer of `steps` extra forwards (same launches rocprof sees)."""
@@ -60,8 +106,23 @@ def time_dominant_kernel(model, tokens, batch, steps=3):
     return sum(ts) / len(ts) * 1e-3
 
 
+def measured_counters(build_id: str, workload: str):
+    """PMC figures of the dominant kernel from profiles/r02_pmc_bench.json, only when that profile was taken with
+    the binary that is running now and on this workload; otherwise (None, reason)."""
+    try:
+        prof = json.load(open(PMC_PROFILE))
+    except (OSError, ValueError) as e:
+        return None, f"no PMC profile ({type(e).__name__})"
+    if prof.get("build_id") != build_id:
+        return None, f"PMC profile is from build {prof.get('build_id')}, this binary is {build_id}"
+    if prof.get("config") != workload:
+        return None, f"PMC profile is for config {prof.get('config')}"
+    return prof, "profiles/r02_pmc_bench.json (rocprofv3 --pmc, separate passes, this binary)"
+
+
 def cpu_baseline(weights, n_seqs=16):
     """Oracle (port of the reference's fp32 path) on a bounded sample: n_seqs x 512 residues, all 36 layers."""
+    import torch
     from esm_amd import synth
     from oracle import trunk_ref  # checker / baseline only
     tok = synth.synth_tokens([SEQ_LEN] * n_seqs, seed=4321)
@@ -74,43 +135,89 @@ def cpu_baseline(weights, n_seqs=16):
             "sample": f"{n_seqs} x {SEQ_LEN} residues, ESM C 600M-shaped fp32, one pass, {dt:.1f} s"}
 
 
+def c4_lengths():
+    import numpy as np
+    rng = np.random.default_rng(C4_SEED)
+    return np.exp(rng.uniform(np.log(C4_LMIN), np.log(C4_LMAX), C4_SEQS)).astype(int).tolist()
+
+
+def fail(msg: str):
+    print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+    raise SystemExit(3)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", choices=["c2", "c4"], default="c2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / rendezvous check without a GPU: workers form the gloo control plane, rank 0 prints a line")
+    ap.add_argument("--rehearsal-shared-gpu", action="store_true",
+                    help="allow more ranks than GPUs (1-GPU rehearsal): the gather then goes through host memory on "
+                         "gloo and the line says so; never used for a reported number")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 10 if args.config == "c2" else 3
+    if args.warmup is None:
+        args.warmup = 3 if args.config == "c2" else 1
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args.gpus))  # this process stays off the GPU
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(n_dev, 1)  # one rank per GPU on a real node; ranks share a GPU only in rehearsals
-    torch.cuda.set_device(dev_index)
+        fail(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import datetime
+
+    import torch
+    import torch.distributed as dist_mod
+
     dist = None
-    nccl_ok = False
+    if args.dry_run:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist_mod.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+            t = torch.tensor([float(rank)])
+            dist_mod.all_reduce(t)
+            assert t.item() == world * (world - 1) / 2
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "launcher": "self" if os.environ.get("ESM_AMD_BENCH_CHILD") else "external"}), flush=True)
+        if world > 1:
+            dist_mod.destroy_process_group()
+        return
+
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0:
+        fail("no GPU visible")
+    shared = n_dev < world
+    if shared and not args.rehearsal_shared_gpu:
+        fail(f"{world} ranks but only {n_dev} GPU(s): one rank per GPU is required (RCCL cannot put two ranks on one "
+             "device); --rehearsal-shared-gpu exists for 1-GPU rehearsals")
+    dev_index = local_rank % n_dev
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        import torch.distributed as dist
+        dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         # control plane (barrier, max-over-ranks of the elapsed time) on gloo: the timing contract must not depend
-        # on the data-plane collective; RCCL ("nccl") carries only the result all-gather.
+        # on the data-plane collective; RCCL ("nccl") carries the result gather.  No fallback: a failure ends the run.
         try:
-            import datetime
-            dist.init_process_group("cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=300))
-            nccl_ok = n_dev >= world
-        except Exception:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo" if shared else "cpu:gloo,cuda:nccl", timeout=datetime.timedelta(seconds=300))
+        except Exception as e:  # noqa: BLE001
+            fail(f"init_process_group failed on rank {rank}: {type(e).__name__}: {e}")
 
-    from esm_amd import synth
+    from esm_amd import _lib, synth
+    from esm_amd.dp import esmc_compute_fn, run_data_parallel
     from esm_amd.engine import DeviceBatch
     from esm_amd.esmc import ESMC
     from esm_amd.packing import pack_lengths
 
+    build_id = _lib.lib().esmk_build_id().decode()
     dev = torch.device("cuda", dev_index)
     weights = synth.esmc_weights(D_MODEL, N_LAYERS, seed=0)
     model = ESMC(D_MODEL, N_HEADS, N_LAYERS)
@@ -118,60 +225,117 @@ def main():
     model = model.to(dev)
     model._engines()
 
-    n_tok = BATCH * SEQ_LEN
-    tokens = synth.synth_tokens([SEQ_LEN] * BATCH, seed=1234 + 1000 * rank).reshape(-1).to(dev)
-    batch = DeviceBatch(pack_lengths([SEQ_LEN] * BATCH), dev)
-
-    gather = (world > 1) and nccl_ok and not args.no_gather
-    side = torch.cuda.Stream() if gather else None
-    gathered = torch.empty((world * n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
-    send = torch.empty((n_tok, D_MODEL), dtype=torch.bfloat16, device=dev) if gather else None
-    gather_note = "off" if (world == 1 or args.no_gather) else ("off: fewer GPUs than ranks" if not nccl_ok else "pending")
-
-    def do_gather(post):
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            send.copy_(post)  # fp32 -> bf16 wire format
-            dist.all_gather_into_tensor(gathered, send)
-        post.record_stream(side)
-
-    def step():
-        logits, post, _ = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=True)
-        if gather:
-            do_gather(post)
-        return logits
-
-    if gather:  # pre-flight: one gather, fully synchronised, before anything is timed; failure -> measure without it
-        try:
-            _l, post0, _h = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=False)
-            do_gather(post0)
-            side.synchronize()
-            torch.cuda.synchronize()
-            gather_note = "all_gather_into_tensor of bf16 per-residue embeddings on a side stream (RCCL), overlapped with the next step"
-        except Exception as e:
-            gather = False
-            gather_note = f"failed in pre-flight: {type(e).__name__}: {e}"[:200]
-    if dist is not None:  # every rank must agree on whether the collective is part of the step
-        flag = torch.tensor([1.0 if gather else 0.0])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if gather and flag.item() == 0.0:
-            gather = False
-            gather_note = "off: pre-flight failed on another rank"
-
     def sync_all():
-        if side is not None:
-            torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         if dist is not None:
             dist.all_reduce(torch.zeros(1))  # barrier on the gloo control plane (CPU tensor)
         torch.cuda.synchronize()
 
+    n_tok = BATCH * SEQ_LEN
+    tokens = synth.synth_tokens([SEQ_LEN] * BATCH, seed=1234 + 1000 * rank).reshape(-1).to(dev)
+    batch = DeviceBatch(pack_lengths([SEQ_LEN] * BATCH), dev)
+
+    if args.config == "c2":
+        gather = world > 1
+        side = torch.cuda.Stream() if gather else None
+        if gather and shared:  # rehearsal only: host round trip on gloo
+            send_h = torch.empty((n_tok, D_MODEL), dtype=torch.bfloat16).pin_memory()
+            gathered_h = torch.empty((world * n_tok, D_MODEL), dtype=torch.bfloat16)
+            gather_note = "REHEARSAL: ranks share a GPU, gather through host memory on gloo (not RCCL)"
+        elif gather:
+            gathered = torch.empty((world * n_tok, D_MODEL), dtype=torch.bfloat16, device=dev)
+            send = torch.empty((n_tok, D_MODEL), dtype=torch.bfloat16, device=dev)
+            gather_note = "all_gather_into_tensor of bf16 per-residue embeddings on a side stream (RCCL), overlapped with the next step"
+        else:
+            gather_note = "off (one rank)"
+
+        def do_gather(post):
+            if shared:
+                send_h.copy_(post)  # synchronous device -> host copy with the bf16 cast
+                dist.all_gather_into_tensor(gathered_h, send_h)
+                return
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                send.copy_(post)  # fp32 -> bf16 wire format
+                dist.all_gather_into_tensor(gathered, send)
+            post.record_stream(side)
+
+        def step():
+            logits, post, _ = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=True)
+            if gather:
+                do_gather(post)
+            return logits
+
+        if gather:  # pre-flight: one gather, fully synchronised and checked, before anything is timed
+            try:
+                _l, post0, _h = model.forward_packed(tokens, batch, want_hiddens=False, want_logits=False)
+                do_gather(post0)
+                if side is not None:
+                    side.synchronize()
+                torch.cuda.synchronize()
+                got = (gathered_h if shared else gathered)[rank * n_tok:(rank + 1) * n_tok]
+                if not torch.equal(got.cpu(), post0.to(torch.bfloat16).cpu()):
+                    raise RuntimeError("gathered block of this rank differs from what it sent")
+            except Exception as e:  # noqa: BLE001
+                fail(f"pre-flight result gather failed on rank {rank}: {type(e).__name__}: {e}")
+
+        def sync_step_streams():
+            if side is not None:
+                torch.cuda.current_stream().wait_stream(side)
+
+        residues_per_step = world * n_tok
+        workload = ("ESM C 600M-shaped (d1152, 18 heads, 36 layers, random init) forward incl. sequence head, "
+                    "64 x L=512 residues per GPU (BASELINE.json configs[1])")
+        cfg = {"workload": workload, "global_batch": world * BATCH, "seq_len": SEQ_LEN, "parallelism": f"dp{world}",
+               "result_gather": gather_note}
+        scaling = "weak"
+        fpr_total = residues_per_step * flop_per_residue()
+    else:  # c4
+        lengths = c4_lengths()
+        seqs = [synth.synth_tokens([n], seed=50000 + i)[0] for i, n in enumerate(lengths)]
+        compute = esmc_compute_fn(model)
+        mode = "none" if world == 1 else "all"
+        if shared:
+            fail("--config c4 has no shared-GPU rehearsal mode")
+        stats = {}
+        sink = torch.zeros(D_MODEL, dtype=torch.float32, device=dev)
+
+        def consume(idx, parts):  # stand-in for the caller's use of the results: touch every gathered byte once
+            for t in parts:
+                sink.add_(t.sum(dim=0, dtype=torch.float32))
+
+        def step():
+            run_data_parallel(seqs, compute, D_MODEL, d=D_MODEL, h=FFN_H, token_budget=C4_BUDGET, device=dev,
+                              wire_dtype=torch.bfloat16, gather=mode, consume=consume, stats=stats)
+
+        def sync_step_streams():
+            pass
+
+        if world > 1:
+            try:
+                run_data_parallel(seqs[:2 * world], compute, D_MODEL, d=D_MODEL, h=FFN_H, token_budget=C4_BUDGET, device=dev,
+                                  wire_dtype=torch.bfloat16, gather="all", consume=consume)
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                fail(f"pre-flight result gather failed on rank {rank}: {type(e).__name__}: {e}")
+        residues_per_step = int(sum(lengths))
+        workload = (f"ESM C 600M-shaped forward (embeddings, no head) of {C4_SEQS} synthetic sequences, L log-uniform in "
+                    f"[{C4_LMIN}, {C4_LMAX}] (seed {C4_SEED}), packs <= {C4_BUDGET} tokens, sharded by esm_amd.dp "
+                    "(BASELINE.json configs[3])")
+        cfg = {"workload": workload, "sequences": C4_SEQS, "tokens_per_step": residues_per_step,
+               "parallelism": f"dp{world}", "result_gather":
+               "off (one rank)" if world == 1 else "all_gather_into_tensor per round on a side stream (RCCL), overlapped with the next pack"}
+        scaling = "strong"
+        fpr_total = float(sum(n * flop_per_residue(L=n) - n * (2 * D_MODEL * D_MODEL + 2 * D_MODEL * 64) for n in lengths))
+
     for _ in range(args.warmup):
         step()
+    sync_step_streams()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    sync_step_streams()
     sync_all()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -181,29 +345,44 @@ def main():
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        value = world * n_tok * args.steps / elapsed
-        fpr = flop_per_residue()
+        value = residues_per_step * args.steps / elapsed
         kt = time_dominant_kernel(model, tokens, batch)
         kflop = 2.0 * n_tok * (2 * FFN_H) * D_MODEL
         achieved = kflop / kt / 1e12
+        prof, prof_note = measured_counters(build_id, "c2")
         line = {
-            "metric": "residues/sec ESM C 600M fwd at L=512", "value": value, "unit": "residues/s",
+            "metric": "residues/sec ESM C 600M fwd at L=512" if args.config == "c2" else "residues/sec ESM C 600M embedding, varlen L 64-2048",
+            "value": value, "unit": "residues/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "ESM C 600M-shaped (d1152, 18 heads, 36 layers, random init) forward incl. "
-                                   "sequence head, 64 x L=512 residues per GPU (BASELINE.json configs[1])",
-                       "global_batch": world * BATCH, "seq_len": SEQ_LEN, "parallelism": f"dp{world}",
-                       "result_gather": gather_note},
-            "mfma_frac_end_to_end": value / world * fpr / (PEAK_TFLOPS * 1e12),
-            "flop_per_residue": fpr,
-            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<SWIGLU> (FFN up-projection 32768x6144x1152)",
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": cfg, "build_id": build_id,
+            "mfma_frac_end_to_end": fpr_total * args.steps / elapsed / world / (PEAK_TFLOPS * 1e12),
+            "flop_per_residue": flop_per_residue() if args.config == "c2" else fpr_total / residues_per_step,
+            "roofline": {"bound": "mfma", "kernel": "gemm256_kernel<SWIGLU> (FFN up-projection 32768x6144x1152, measured on the 64 x 512 batch)",
                          "achieved": achieved, "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS,
-                         "traffic": DOMINANT_KERNEL_HBM_BYTES, "traffic_unit": "bytes/launch (PMC, profiles/r01_pmc_gemm_ffn1.json)",
+                         "traffic": prof["dominant_kernel"]["hbm_bytes_per_launch"] if prof else None,
+                         "traffic_unit": "bytes/launch", "traffic_source": prof_note,
+                         "algorithmic_bytes": 2 * (n_tok * D_MODEL + 2 * FFN_H * D_MODEL + n_tok * FFN_H),
                          "launch_ms": kt * 1e3,
-                         "mfma_busy_frac_at_held_clock": DOMINANT_KERNEL_MFMA_BUSY,
-                         "mfma_busy_source": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES, GRBM_GUI_ACTIVE "
-                                             "(profiles/r01_pmc_mfma_util.json)"},
+                         "mfma_busy_frac_at_held_clock": prof["dominant_kernel"].get("mfma_busy_frac") if prof else None},
         }
+        if args.config == "c2":
+            # the same batch through the reference's public entry point (ESMC.logits on a [64, 512] token matrix with
+            # LogitsConfig(sequence, return_embeddings)): batch description on the device, output masking included
+            from esm_amd.api import LogitsConfig, _BatchedESMProteinTensor
+            inp = _BatchedESMProteinTensor(sequence=tokens.view(BATCH, SEQ_LEN))
+            lcfg = LogitsConfig(sequence=True, return_embeddings=True)
+            for _ in range(2):
+                model.logits(inp, lcfg)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(5):
+                model.logits(inp, lcfg)
+            torch.cuda.synchronize()
+            line["api_residues_per_s"] = 5 * n_tok / (time.perf_counter() - ta)
+            line["api_note"] = "ESMC.logits(_BatchedESMProteinTensor[64, 512], LogitsConfig(sequence, return_embeddings)), 5 calls, one GPU"
+        if args.config == "c4":
+            line["dp"] = stats
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(weights)
         print(json.dumps(line), flush=True)

@@ -41,7 +41,7 @@ class EsmkTrunk(C.Structure):
 class EsmkBatch(C.Structure):
     _fields_ = [("n_tokens", C.c_int), ("n_segments", C.c_int), ("cu_seqlens", vp), ("positions", vp),
                 ("qblk_map", vp), ("n_qblk", C.c_int), ("affine", vp), ("affine_mask", vp), ("seq_id", vp),
-                ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int)]
+                ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int), ("pad_tail", C.c_int)]
 
 
 class EsmkHead(C.Structure):
@@ -76,6 +76,8 @@ SIGNATURES = {
     "esmk_vq_quantize": (C.c_int, [vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esmk_trunk_workspace_bytes": (C.c_size_t, [C.POINTER(EsmkTrunk), C.c_int]),
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
+    "esmk_trunk_forward_ex": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, C.c_int, vp, C.c_size_t, vp]),
+    "esmk_segments_from_tokens": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "esmk_sample_track": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]),
     "esmk_dim6_frames": (C.c_int, [vp, C.c_int, C.c_float, vp, vp, C.c_int, vp]),

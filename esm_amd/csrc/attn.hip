@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
                                                             __bf16* __restrict__ ctx,
                                                             const int* __restrict__ cu_seqlens,
                                                             const int* __restrict__ qblk_map, int n_qblk, int d,
-                                                            int H, int nblk) {
+                                                            int H, int nblk, int pad_tail) {
     __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // [buf][K | V]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int id = xcd_remap(blockIdx.x, nblk);
@@ -36,6 +36,18 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
     const int len = s1 - s0;
     const size_t ld = (size_t)3 * d;
     const int l31 = lane & 31, hi = lane >> 5;
+    // pad_tail (batches described on the device, esmk_segments_from_tokens): segment `seg` is the valid prefix of a
+    // padded row and segment seg+1 its padding; the query blocks of the row span both, rows past `len` get zeros
+    const int tail_end = pad_tail ? cu_seqlens[seg + 2] - s0 : len;
+    if (q0 >= len) {  // whole block is padding (or lies beyond the row): block-uniform exit before any barrier
+        const int qr = q0 + wave * 32 + l31;
+        if (qr < tail_end) {
+            u32x4* op = (u32x4*)(ctx + (size_t)(s0 + qr) * d + head * 64 + hi * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) op[i] = u32x4{0u, 0u, 0u, 0u};
+        }
+        return;
+    }
 
     // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = l31][dh = 16ks + 8hi + j] ----
     bf16x8 qf[4];
@@ -172,6 +184,11 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
     lsum += __shfl_xor(lsum, 32);
     const float inv = 1.0f / lsum;
     const int qr = q0 + wave * 32 + l31;
+    if (qr >= len && qr < tail_end) {
+        u32x4* zp = (u32x4*)(ctx + (size_t)(s0 + qr) * d + head * 64 + hi * 32);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) zp[i] = u32x4{0u, 0u, 0u, 0u};
+    }
     if (qr < len) {
         __bf16* op = ctx + (size_t)(s0 + qr) * d + head * 64;
 #pragma unroll
@@ -206,8 +223,17 @@ extern "C" int esmk_attn_plan(const int32_t* cu, int n_segments, int32_t* map, i
     return n;
 }
 
+int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map, int n_qblk,
+                          int M, int d, int H, int pad_tail, esmk_stream_t stream);
+
 extern "C" int esmk_attn_varlen(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map,
                                 int n_qblk, int M, int d, int H, esmk_stream_t stream) {
+    return esmk_attn_varlen_impl(qkv, ctx, cu_seqlens, qblk_map, n_qblk, M, d, H, 0, stream);
+}
+
+// pad_tail = 1: the batch layout of esmk_segments_from_tokens (esmk_batch.pad_tail)
+int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map, int n_qblk,
+                          int M, int d, int H, int pad_tail, esmk_stream_t stream) {
     if (n_qblk == 0 || M == 0) return ESMK_OK;
     if (!qkv || !ctx || !cu_seqlens || !qblk_map) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen: null pointer");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen: head dim must be 64 (d=%d, heads=%d)", d, H);
@@ -216,7 +242,7 @@ extern "C" int esmk_attn_varlen(const void* qkv, void* ctx, const int32_t* cu_se
     const long long nblk = (long long)n_qblk * H;
     if (nblk > 0x7fffffffLL) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen: grid too large");
     hipLaunchKernelGGL(attn_varlen_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk);
+                       (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail);
     ESMK_CHECK_LAUNCH("esmk_attn_varlen");
     return ESMK_OK;
 }

@@ -464,6 +464,52 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
     return ESMK_OK;
 }
 
+// Device-side batch description of a right-padded [B, L] token matrix (esmk_segments_from_tokens): one block per row.
+__global__ __launch_bounds__(256) void segments_from_tokens_kernel(const int64_t* __restrict__ tokens,
+                                                                   const uint8_t* __restrict__ mask, int L, long long pad_id,
+                                                                   int vocab, int B, int* __restrict__ cu,
+                                                                   int* __restrict__ err) {
+    __shared__ int s_len, s_bad;
+    const int b = blockIdx.x;
+    if (threadIdx.x == 0) { s_len = 0; s_bad = 0; }
+    __syncthreads();
+    int len = 0, bad = 0;
+    const int64_t* row = tokens + (size_t)b * L;
+    for (int i = threadIdx.x; i < L; i += blockDim.x) {
+        const long long t = row[i];
+        const bool v = mask ? mask[(size_t)b * L + i] != 0 : t != pad_id;
+        if (v) {
+            ++len;
+            if (i > 0) {  // a real token behind a padding position: the row is not right-padded
+                const bool pv = mask ? mask[(size_t)b * L + i - 1] != 0 : row[i - 1] != pad_id;
+                if (!pv) ++bad;
+            }
+        }
+        if (t < 0 || t >= vocab) ++bad;
+    }
+    if (len) atomicAdd(&s_len, len);
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cu[2 * b] = b * L;
+        cu[2 * b + 1] = b * L + s_len;
+        if (b == B - 1) cu[2 * B] = B * L;
+        if (s_bad && err) atomicAdd(err, s_bad);
+    }
+}
+
+extern "C" int esmk_segments_from_tokens(const int64_t* tokens, const uint8_t* mask, int B, int L, int64_t pad_id,
+                                         int vocab, int32_t* cu_seqlens, int32_t* err_count, esmk_stream_t stream) {
+    if (B == 0) return ESMK_OK;
+    if (!tokens || !cu_seqlens) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_segments_from_tokens: null pointer");
+    if (B < 0 || L <= 0 || vocab <= 0 || (long long)B * L > 0x7fffffffLL)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_segments_from_tokens: bad sizes B=%d L=%d", B, L);
+    hipLaunchKernelGGL(segments_from_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, mask, L,
+                       (long long)pad_id, vocab, B, cu_seqlens, err_count);
+    ESMK_CHECK_LAUNCH("esmk_segments_from_tokens");
+    return ESMK_OK;
+}
+
 extern "C" int esmk_segment_mean(const float* x, int ldx, const int32_t* cu_seqlens, int n_segments, float* out, int d,
                                  esmk_stream_t stream) {
     if (n_segments == 0) return ESMK_OK;

@@ -11,6 +11,8 @@
 static thread_local char g_err[512] = "";
 
 int esmk_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
+int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map, int n_qblk,
+                          int M, int d, int H, int pad_tail, esmk_stream_t stream);
 
 void esmk_set_error(const char* fmt, ...) {
     va_list ap;
@@ -91,7 +93,14 @@ extern "C" size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens) 
 
 extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
                                   void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
+    return esmk_trunk_forward_ex(t, b, x, post_norm, hiddens, -1, workspace, workspace_bytes, stream);
+}
+
+extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
+                                     int hidden_layer, void* workspace, size_t workspace_bytes, esmk_stream_t stream) {
     TRY(validate_trunk(t));
+    if (hiddens && (hidden_layer < -1 || hidden_layer >= t->n_layers))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: hidden_layer %d outside [-1, %d)", hidden_layer, t->n_layers);
     if (!b) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null batch");
     if (b->n_tokens == 0) return ESMK_OK;
     if (!x) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: null x");
@@ -139,13 +148,14 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
             ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
         // --- x += MHA(x) / s  (attention.py:48-82, blocks.py:146-148)
         TRY(flush_ln(L.ln1_g, L.ln1_b, xn, ESMK_BF16));
-        if (hiddens && i > 0) {  // x now holds block i-1's output
-            if (hipMemcpyAsync(hiddens + (size_t)(i - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+        if (hiddens && i > 0 && (hidden_layer < 0 || hidden_layer == i - 1)) {  // x now holds block i-1's output
+            float* dst = hidden_layer < 0 ? hiddens + (size_t)(i - 1) * M * d : hiddens;
+            if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
                 ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
         }
         TRY(esmk_gemm_ws(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, skp, w.splitk_bytes, stream));
         TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
-        TRY(esmk_attn_varlen(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, stream));
+        TRY(esmk_attn_varlen_impl(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, b->pad_tail ? 1 : 0, stream));
         TRY(esmk_gemm_ws(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbufA, skp, w.splitk_bytes, stream));
         pa = dbufA;
         // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)
@@ -176,8 +186,9 @@ extern "C" int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, floa
     // final: fold the last delta into x (pre-norm output) and normalise (transformer_stack.py:94)
     void* post = post_norm ? (void*)post_norm : xn;
     TRY(flush_ln(t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16));
-    if (hiddens) {
-        if (hipMemcpyAsync(hiddens + (size_t)(t->n_layers - 1) * M * d, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    if (hiddens && (hidden_layer < 0 || hidden_layer == t->n_layers - 1)) {
+        float* dst = hidden_layer < 0 ? hiddens + (size_t)(t->n_layers - 1) * M * d : hiddens;
+        if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
     }
     return ESMK_OK;

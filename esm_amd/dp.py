@@ -8,8 +8,9 @@ Host logic (this file, torch.distributed for the one collective):
      bounds the 4*L*d attention-term imbalance),
   2. assign packs to ranks, longest-processing-time-first, on the FLOP cost model of SURVEY.md 8(d):
        cost(seq of length L) = L*(8d^2 + 6dh) + 4d*L^2   per layer,
-  3. every rank runs its packs through `compute_fn` (the HIP trunk),
-  4. ONE all-gather of the per-residue results (padded to the largest rank) + the permutation to undo.
+  3. every rank runs its packs through `compute_fn` (the HIP trunk), one pack per round,
+  4. the per-residue results of a round are gathered (to all ranks or to rank 0) while the next round computes;
+     two buffer pairs alternate, the permutation is undone as results are handed over.
 
 With backend "nccl" the collective is RCCL over xGMI; the same code runs on "gloo" for the CPU tests.
 """
@@ -65,44 +66,119 @@ def plan(lengths: Sequence[int], world_size: int, token_budget: int, d: int, h: 
 
 
 def run_data_parallel(sequences: Sequence[torch.Tensor], compute_fn: Callable, width: int, d: int, h: int,
-                      token_budget: int = 32768, device=None, wire_dtype=torch.bfloat16, group=None):
-    """Embed `sequences` (1-D int64 token tensors, identical on every rank) data-parallel.
+                      token_budget: int = 32768, device=None, wire_dtype=torch.bfloat16, group=None,
+                      gather: str = "all", consume: Callable | None = None, stats: dict | None = None):
+    """Embed `sequences` (1-D int64 token tensors, identical on every rank) data-parallel, streaming.
 
     compute_fn(tokens_packed [N] on `device`, lengths list[int]) -> [N, width] tensor on `device`.
-    Returns a list (original order) of [L_i, width] tensors in `wire_dtype`, available on EVERY rank.
+
+    The packs of a rank run one after the other; round k = the k-th pack of every rank.  The results of round k
+    travel (one collective per round, sizes known to everyone from the plan - no size exchange) while round k+1
+    computes: on a GPU the collective runs on a side stream, and two send/receive buffer pairs alternate, so at most
+    TWO rounds of results are resident besides what the caller keeps.
+
+    gather  "all"   every rank receives every result (all_gather_into_tensor, RCCL with backend nccl)
+            "root"  only rank 0 receives them (dist.gather); other ranks return None for every sequence
+            "none"  no collective: a rank keeps the results of its own sequences (None for the others)
+    consume optional callback consume(indices list[int], tensors list[[L_i, width]]) called once per round and source
+            rank with results that are only valid during the call (views into a buffer that is reused two rounds
+            later): pool, write out or copy them there.  With a callback nothing is retained and the function
+            returns None - this is the form for large jobs (config C4: 4096 sequences would otherwise be several
+            GB per rank).
+    stats   optional dict, filled with {"rounds", "peak_resident_rounds", "buffer_bytes", "collectives"}.
+    Without `consume`: returns a list (original order) of [L_i, width] tensors in `wire_dtype` (copies).
     """
+    if gather not in ("all", "root", "none"):
+        raise ValueError("gather must be 'all', 'root' or 'none'")
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     lengths = [int(s.numel()) for s in sequences]
     packs, per_rank, _ = plan(lengths, world, token_budget, d, h)
-    device = device or torch.device("cpu")
-    # local compute
-    chunks = []
-    for p in per_rank[rank]:
-        idx = packs[p]
-        toks = torch.cat([sequences[i] for i in idx]).to(device)
-        out = compute_fn(toks, [lengths[i] for i in idx])
-        chunks.append(out.to(wire_dtype))
-    local = torch.cat(chunks) if chunks else torch.zeros((0, width), dtype=wire_dtype, device=device)
-    # token counts per rank are known to everyone from the plan: no size exchange needed
-    counts = [sum(lengths[i] for p in per_rank[r] for i in packs[p]) for r in range(world)]
-    if world > 1:
-        cap = max(counts)
-        send = torch.zeros((cap, width), dtype=wire_dtype, device=device)
-        send[: local.shape[0]] = local
-        recv = torch.empty((world * cap, width), dtype=wire_dtype, device=device)
-        dist.all_gather_into_tensor(recv, send, group=group)
-        per = [recv[r * cap: r * cap + counts[r]] for r in range(world)]
-    else:
-        per = [local]
-    # undo the permutation
-    results = [None] * len(sequences)
-    for r in range(world):
-        off = 0
-        for p in per_rank[r]:
-            for i in packs[p]:
-                results[i] = per[r][off: off + lengths[i]]
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    on_gpu = device.type == "cuda"
+    n_rounds = max((len(p) for p in per_rank), default=0)
+    # tokens of rank r in round k (0 when it has run out of packs): known to every rank from the plan
+    count = lambda r, k: sum(lengths[i] for i in packs[per_rank[r][k]]) if k < len(per_rank[r]) else 0
+    cap = max((count(r, k) for r in range(world) for k in range(n_rounds)), default=0)
+    collective = world > 1 and gather != "none"
+    results = None if consume is not None else [None] * len(sequences)
+    st = {"rounds": n_rounds, "peak_resident_rounds": 0, "buffer_bytes": 0, "collectives": 0}
+
+    send = [torch.empty((cap, width), dtype=wire_dtype, device=device) for _ in range(2)]
+    recv = None
+    if collective and (gather == "all" or rank == 0):
+        recv = [torch.empty((world * cap, width), dtype=wire_dtype, device=device) for _ in range(2)]
+    st["buffer_bytes"] = sum(t.numel() * t.element_size() for t in send + (recv or []))
+    side = torch.cuda.Stream(device=device) if (on_gpu and collective) else None
+    done = [None, None]   # per buffer pair: event (GPU) marking the end of its collective
+    resident = 0
+
+    def deliver(k):
+        """Hand round k's results to the caller (consume) or copy them into the retained list."""
+        nonlocal resident
+        slot = k & 1
+        if side is not None:
+            torch.cuda.current_stream(device).wait_event(done[slot])
+        if collective:
+            srcs = range(world) if recv is not None else ()
+            view = lambda r: recv[slot][r * cap: r * cap + count(r, k)]
+        else:
+            srcs = (rank,)
+            view = lambda r: send[slot][: count(r, k)]
+        for r in srcs:
+            if k >= len(per_rank[r]):
+                continue
+            idx = packs[per_rank[r][k]]
+            buf, off, parts = view(r), 0, []
+            for i in idx:
+                parts.append(buf[off: off + lengths[i]])
                 off += lengths[i]
+            if consume is not None:
+                consume(idx, parts)
+            else:
+                for i, t in zip(idx, parts):
+                    results[i] = t.clone()
+        resident -= 1
+
+    for k in range(n_rounds):
+        slot = k & 1
+        # buffers of this slot were last used by round k-2, which was handed over in iteration k-1
+        n = count(rank, k)
+        if n:
+            idx = packs[per_rank[rank][k]]
+            toks = torch.cat([sequences[i] for i in idx]).to(device, non_blocking=True)
+            out = compute_fn(toks, [lengths[i] for i in idx])
+            send[slot][:n].copy_(out)   # cast to the wire dtype; the pack's own output is dropped right here
+            del out
+        resident += 1
+        st["peak_resident_rounds"] = max(st["peak_resident_rounds"], resident)
+        if collective:
+            if side is not None:
+                side.wait_stream(torch.cuda.current_stream(device))
+                ctx = torch.cuda.stream(side)
+            else:
+                import contextlib
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if gather == "all":
+                    dist.all_gather_into_tensor(recv[slot], send[slot], group=group)
+                else:
+                    parts = list(recv[slot].view(world, cap, width).unbind(0)) if rank == 0 else None
+                    dist.gather(send[slot], parts, dst=0, group=group)
+                if side is not None:
+                    done[slot] = torch.cuda.Event()
+                    done[slot].record(side)
+            st["collectives"] += 1
+        # round k's collective is now in flight (GPU: on the side stream) while we hand over round k-1; the next
+        # iteration's compute is enqueued behind that hand-over and runs beside round k's collective
+        if k >= 1:
+            deliver(k - 1)
+    if n_rounds:
+        deliver(n_rounds - 1)
+    if side is not None:
+        torch.cuda.current_stream(device).wait_stream(side)
+    if stats is not None:
+        stats.update(st)
     return results
 
 

@@ -70,7 +70,41 @@ class DeviceBatch:
         d.row_cu = L.ptr(self.row_cu)
         d.n_rows = pb.B
         d.max_row_len = pb.max_row_len
+        d.pad_tail = 0
         self.desc = d
+
+    _padded_static: dict = {}
+
+    @classmethod
+    def padded(cls, B: int, Ln: int, cu_seqlens: torch.Tensor, device) -> "DeviceBatch":
+        """Batch of a right-padded [B, L] token matrix whose row lengths are known on the DEVICE only
+        (esmk_segments_from_tokens): all B*L positions stay packed, `cu_seqlens` int32 [2B+1] holds (valid prefix,
+        padding) segment pairs, everything else depends on (B, L) alone and is cached per device - building it costs
+        no host synchronisation."""
+        device = torch.device(device)
+        key = (B, Ln, device.type, device.index if device.index is not None else torch.cuda.current_device())
+        st = cls._padded_static.get(key)
+        if st is None:
+            if len(cls._padded_static) >= 16:
+                cls._padded_static.pop(next(iter(cls._padded_static)))
+            nq = (Ln + L.ATTN_QBLK - 1) // L.ATTN_QBLK
+            qmap = np.stack([np.repeat(2 * np.arange(B, dtype=np.int32), nq),
+                             np.tile(np.arange(nq, dtype=np.int32) * L.ATTN_QBLK, B)], axis=1)
+            row_cu = (np.arange(B + 1, dtype=np.int64) * Ln).astype(np.int32)
+            pb = PackedBatch(B, Ln, B * Ln, row_cu, np.tile(np.arange(Ln, dtype=np.int32), B), None, row_cu,
+                             np.zeros(B * Ln, dtype=np.int32), qmap)
+            st = cls(pb, device)
+            cls._padded_static[key] = st
+        self = object.__new__(cls)
+        self.__dict__.update(st.__dict__)
+        self.cu_seqlens = cu_seqlens
+        d = L.EsmkBatch()
+        C.memmove(C.byref(d), C.byref(st.desc), C.sizeof(d))
+        d.cu_seqlens = L.ptr(cu_seqlens)
+        d.n_segments = 2 * B
+        d.pad_tail = 1
+        self.desc = d
+        return self
 
 
 class TrunkEngine:
@@ -163,19 +197,24 @@ class TrunkEngine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward(self, x: torch.Tensor, batch: DeviceBatch, want_post: bool = True, want_hiddens: bool = False):
-        """x f32 [N, d] (modified in place -> pre-norm output).  Returns (post_norm|None, x, hiddens|None)."""
+    def forward(self, x: torch.Tensor, batch: DeviceBatch, want_post: bool = True, want_hiddens: bool = False,
+                hidden_layer: int = -1):
+        """x f32 [N, d] (modified in place -> pre-norm output).  Returns (post_norm|None, x, hiddens|None).
+        hidden_layer >= 0 with want_hiddens: only that block's output is captured, hiddens is [1, N, d]."""
         N = batch.pb.n_tokens
         assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape == (N, self.d)
         if batch.pb.max_position >= self._desc.rope_len:
             self._set_rope(max(2 * self._desc.rope_len, batch.pb.max_position + 1))
         post = torch.empty_like(x) if want_post else None
-        hid = torch.empty((self.n_layers, N, self.d), dtype=torch.float32, device=x.device) if want_hiddens else None
+        if want_hiddens and not -1 <= hidden_layer < self.n_layers:
+            raise IndexError(f"hidden layer {hidden_layer} outside [0, {self.n_layers})")
+        n_hid = self.n_layers if hidden_layer < 0 else 1
+        hid = torch.empty((n_hid, N, self.d), dtype=torch.float32, device=x.device) if want_hiddens else None
         if N == 0:
             return post, x, hid
         ws = self.workspace(N)
-        rc = self.lib.esmk_trunk_forward(C.byref(self._desc), C.byref(batch.desc), L.ptr(x), L.ptr(post), L.ptr(hid),
-                                         L.ptr(ws), ws.numel(), _stream())
+        rc = self.lib.esmk_trunk_forward_ex(C.byref(self._desc), C.byref(batch.desc), L.ptr(x), L.ptr(post), L.ptr(hid),
+                                            hidden_layer, L.ptr(ws), ws.numel(), _stream())
         L.check(rc, "esmk_trunk_forward")
         return post, x, hid
 

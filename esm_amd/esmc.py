@@ -45,6 +45,7 @@ class ESMC(nn.Module):
         self.d_model = d_model
         self._head = None
         self._embed_f32 = None
+        self._token_err = None  # device counter of invalid tokens / rows seen by the device-described path
         self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
 
     def _invalidate(self):
@@ -75,16 +76,24 @@ class ESMC(nn.Module):
 
     # ------------------------------------------------------------------------------------------
     def forward_packed(self, tokens: torch.Tensor, batch: DeviceBatch, want_hiddens: bool = False,
-                       want_logits: bool = True):
-        """tokens int64 [N] (packed, pads already dropped) -> (logits [N,64]|None, post_norm [N,d], hiddens|None)."""
+                       want_logits: bool = True, hidden_layer: int = -1):
+        """tokens int64 [N] (packed) -> (logits [N,64]|None, post_norm [N,d], hiddens|None).
+        hidden_layer >= 0: capture only that block's output (hiddens [1, N, d])."""
         trunk, head = self._engines()
         N = tokens.shape[0]
         x = torch.empty((N, self.d_model), dtype=torch.float32, device=tokens.device)
         L.check(L.lib().esmk_embed(L.ptr(tokens), L.ptr(self._embed_f32), 64, L.ptr(x), N, self.d_model, _stream()),
                 "esmk_embed")
-        post, _pre, hid = trunk.forward(x, batch, want_post=True, want_hiddens=want_hiddens)
+        post, _pre, hid = trunk.forward(x, batch, want_post=True, want_hiddens=want_hiddens, hidden_layer=hidden_layer)
         logits = head.forward(post) if want_logits else None
         return logits, post, hid
+
+    def invalid_token_count(self) -> int:
+        """Tokens outside the 64-row table + rows that were not right-padded, summed over the forwards run on the
+        device-described path since the model was built (synchronises; 0 = every input was valid).  Such tokens are
+        clamped into the table, such rows attend over their leading run only - check this where the reference
+        would have raised."""
+        return 0 if self._token_err is None else int(self._token_err.item())
 
     # ---- text <-> tokens (reference esmc.py:100-115,175-192) ----------------------------------
     def _tokenize(self, sequence: list[str]) -> torch.Tensor:
@@ -109,24 +118,60 @@ class ESMC(nn.Module):
 
     @torch.no_grad()
     def forward(self, sequence_tokens: torch.Tensor | None = None, sequence_id: torch.Tensor | None = None,
-                return_hidden_states: bool = True, _means: dict | None = None) -> ESMCOutput:
+                return_hidden_states: bool = True, _means: dict | None = None, hidden_layer: int = -1,
+                drop_pads: bool = False, validate: bool = False) -> ESMCOutput:
+        """reference esm/models/esmc.py:117-173.  Beyond the reference's arguments:
+        hidden_layer >= 0  capture only that block's output: hidden_states is [1, B, L, d] (LogitsConfig.ith_hidden_layer)
+        drop_pads          pack the non-pad tokens on the host first (one host synchronisation; no arithmetic is spent
+                           on padding - the form for very ragged batches; esm_amd.pipeline does this for bulk jobs)
+        validate           raise IndexError for out-of-range tokens like the reference does (one host synchronisation)
+
+        Default path (sequence_id=None): the batch is described ON THE DEVICE (esmk_segments_from_tokens) - no host
+        synchronisation anywhere in the call; padding positions run through the row-wise kernels, are never attended
+        to, and come back as zeros (the reference's flash path, esmc.py:159-164)."""
         assert sequence_tokens is not None and sequence_tokens.ndim == 2
         B, Ln = sequence_tokens.shape
         dev = sequence_tokens.device
-        if int(sequence_tokens.min()) < 0 or int(sequence_tokens.max()) >= 64:
+        if dev.type != "cuda":
+            raise L.EsmkError("esm_amd runs on the GPU only: pass CUDA tensors (there is no CPU path)")
+        if validate and (int(sequence_tokens.min()) < 0 or int(sequence_tokens.max()) >= 64):
             raise IndexError("sequence_tokens out of range for the 64-row embedding table")
+        flat = sequence_tokens.reshape(-1).to(torch.int64).contiguous()
+        NL = self.transformer.n_layers
+        n_hid = NL if hidden_layer < 0 else 1
+        if sequence_id is None and not drop_pads:
+            # ---- device-described batch: no host synchronisation
+            if self._token_err is None or self._token_err.device != dev:
+                self._token_err = torch.zeros(1, dtype=torch.int32, device=dev)
+            cu = torch.empty(2 * B + 1, dtype=torch.int32, device=dev)
+            L.check(L.lib().esmk_segments_from_tokens(L.ptr(flat), None, B, Ln, PAD_TOKEN_ID, 64, L.ptr(cu),
+                                                      L.ptr(self._token_err), _stream()), "esmk_segments_from_tokens")
+            batch = DeviceBatch.padded(B, Ln, cu, dev)
+            logits, post, hid = self.forward_packed(flat, batch, want_hiddens=return_hidden_states,
+                                                    hidden_layer=hidden_layer)
+            pad = (sequence_tokens == PAD_TOKEN_ID).view(B, Ln, 1)
+            if _means is not None:  # means over the valid prefix of every row = the even segments
+                if _means.get("embedding"):
+                    _means["embedding"] = segment_mean(post, cu)[::2]
+                if _means.get("hidden") and hid is not None:
+                    _means["hidden"] = torch.stack([segment_mean(hid[i], cu)[::2] for i in range(hid.shape[0])])
+            hidden = None
+            if hid is not None:
+                hidden = hid.view(n_hid, B, Ln, self.d_model).masked_fill_(pad[None], 0.0)
+            return ESMCOutput(sequence_logits=logits.view(B, Ln, -1).masked_fill_(pad, 0.0),
+                              embeddings=post.view(B, Ln, -1).masked_fill_(pad, 0.0), hidden_states=hidden)
+        # ---- host-described batch (explicit sequence_id of any dialect, or drop_pads)
         if sequence_id is None:
             sequence_id = sequence_tokens != PAD_TOKEN_ID  # esmc.py:133-135
         assert sequence_id.shape == (B, Ln)
         pb = pack_sequence_id(sequence_id.detach().cpu().numpy(), B, Ln, drop_false=True)
         batch = DeviceBatch(pb, dev)
-        flat = sequence_tokens.reshape(-1).to(torch.int64)
         if pb.gather is not None:
             gidx = torch.from_numpy(pb.gather).to(dev)
             tok = flat[gidx].contiguous()
         else:
-            gidx, tok = None, flat.contiguous()
-        logits, post, hid = self.forward_packed(tok, batch, want_hiddens=return_hidden_states)
+            gidx, tok = None, flat
+        logits, post, hid = self.forward_packed(tok, batch, want_hiddens=return_hidden_states, hidden_layer=hidden_layer)
         if _means is not None:  # per-row means over the kept tokens, on the packed tensors (esmk_segment_mean)
             if _means.get("embedding"):
                 _means["embedding"] = segment_mean(post, batch.row_cu)
@@ -143,11 +188,11 @@ class ESMC(nn.Module):
         hidden = None
         if hid is not None:
             if gidx is None:
-                hidden = hid.view(self.transformer.n_layers, B, Ln, self.d_model)
+                hidden = hid.view(n_hid, B, Ln, self.d_model)
             else:
-                hidden = torch.zeros((self.transformer.n_layers, B * Ln, self.d_model), dtype=hid.dtype, device=dev)
+                hidden = torch.zeros((n_hid, B * Ln, self.d_model), dtype=hid.dtype, device=dev)
                 hidden[:, gidx] = hid
-                hidden = hidden.view(self.transformer.n_layers, B, Ln, self.d_model)
+                hidden = hidden.view(n_hid, B, Ln, self.d_model)
         return ESMCOutput(sequence_logits=unpack(logits), embeddings=unpack(post), hidden_states=hidden)
 
     def logits(self, input: ESMProteinTensor | _BatchedESMProteinTensor,
@@ -157,12 +202,16 @@ class ESMC(nn.Module):
             input = _BatchedESMProteinTensor.from_protein_tensor(input)
         want_hid = config.return_hidden_states or config.return_mean_hidden_states
         means = {"embedding": config.return_mean_embedding, "hidden": config.return_mean_hidden_states}
-        out = self.forward(sequence_tokens=input.sequence, return_hidden_states=want_hid, _means=means)
+        # ith_hidden_layer != -1: only that block's output is ever captured ([1, B, L, d], what the reference's
+        # hidden_states[i:i+1] slice returns, esmc.py:213-218); python-style negative indices count from the end
+        layer = config.ith_hidden_layer
+        if layer != -1 and want_hid:
+            if not -self.transformer.n_layers <= layer < self.transformer.n_layers:
+                raise IndexError(f"ith_hidden_layer {layer} outside the {self.transformer.n_layers} layers")
+            layer %= self.transformer.n_layers
+        out = self.forward(sequence_tokens=input.sequence, return_hidden_states=want_hid, _means=means,
+                           hidden_layer=layer if want_hid else -1)
         hs, mh = out.hidden_states, means["hidden"] if config.return_mean_hidden_states else None
-        if config.ith_hidden_layer != -1:
-            sl = slice(config.ith_hidden_layer, config.ith_hidden_layer + 1)
-            hs = hs[sl] if hs is not None else None
-            mh = mh[sl] if mh is not None else None
         return LogitsOutput(
             logits=ForwardTrackData(sequence=out.sequence_logits if config.sequence else None),
             embeddings=out.embeddings if config.return_embeddings else None,

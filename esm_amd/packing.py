@@ -9,8 +9,9 @@ so every dialect is converted to contiguous segments here (SURVEY.md section 8a,
   bool, drop=True ESM C semantics (esmc.py:133-164): the True positions of a row form one segment, False
                   positions are dropped and come back as zeros (the reference's flash path; its SDPA path
                   leaves unspecified finite values there)
-  int / bool      run-length segments inside each row; an id that re-appears after a different id in the same
-                  row would need a dense mask and raises NotImplementedError
+  int / bool      run-length segments inside each row; when an id re-appears after a different id in the same row
+                  (a general equality mask), the row's tokens are stably sorted by id first - `gather` is then that
+                  permutation, positions keep the original columns, and callers scatter outputs back
 
 Rotary position = COLUMN index in the [B, L] row, as in the reference's SDPA path (rotary.py:207-209,54-56).
 Everything here is numpy on the host and is covered by CPU tests.
@@ -84,22 +85,32 @@ def pack_sequence_id(sequence_id, B: int, L: int, drop_false: bool = False) -> P
         pb.qblk_map = plan_attention(pb.cu_seqlens)
         return pb
     ids = sid.astype(np.int64)
-    # run boundaries: row starts and positions where the id changes
-    change = np.ones((B, L), dtype=bool)
-    change[:, 1:] = ids[:, 1:] != ids[:, :-1]
-    starts = np.nonzero(change.reshape(-1))[0]
-    cu = np.concatenate([starts, [B * L]]).astype(np.int32)
-    # contiguity: within a row no id may start two runs
-    run_row = starts // L
-    run_id = ids.reshape(-1)[starts]
-    key = np.stack([run_row, run_id], axis=1)
+
+    def runs(flat_ids):
+        """Run boundaries: row starts and positions where the id changes -> (starts, one (row, id) key per run)."""
+        m = flat_ids.reshape(B, L)
+        change = np.ones((B, L), dtype=bool)
+        change[:, 1:] = m[:, 1:] != m[:, :-1]
+        st = np.nonzero(change.reshape(-1))[0]
+        return st, np.stack([st // L, flat_ids[st]], axis=1)
+
+    flat = ids.reshape(-1)
+    starts, key = runs(flat)
+    gather = None
     if len(np.unique(key, axis=0)) != len(key):
-        raise NotImplementedError(
-            "sequence_id repeats an id in non-adjacent runs of one row; only contiguous (bin-packed) ids are supported")
+        # an id re-appears in a non-adjacent run of its row (general equality mask, attention.py:67).  Everything
+        # but attention is per-token and attention is permutation-invariant inside a segment once every token
+        # carries its own rotary position, so: stable-sort each row by id (equal ids become one contiguous
+        # segment), keep the original column as the position, and let the caller scatter the outputs back.
+        gather = np.lexsort((np.tile(np.arange(L), B), flat, np.repeat(np.arange(B), L))).astype(np.int64)
+        flat = flat[gather]
+        starts, key = runs(flat)
+        assert len(np.unique(key, axis=0)) == len(key)
+    cu = np.concatenate([starts, [B * L]]).astype(np.int32)
     row_cu = (np.arange(B + 1, dtype=np.int64) * L).astype(np.int32)
     # per-token label: equality of labels inside a row must equal equality of ids -> use the id itself (mod 2^31)
-    seq_lab = (ids.reshape(-1) & 0x7FFFFFFF).astype(np.int32)
-    pb = PackedBatch(B, L, B * L, cu, cols, None, row_cu, seq_lab)
+    seq_lab = (flat & 0x7FFFFFFF).astype(np.int32)
+    pb = PackedBatch(B, L, B * L, cu, cols if gather is None else cols[gather], gather, row_cu, seq_lab)
     pb.qblk_map = plan_attention(pb.cu_seqlens)
     return pb
 

@@ -142,8 +142,23 @@ class TransformerStack(nn.Module):
             if chain_id is None:
                 chain_id = torch.ones((B, Ln), dtype=torch.int64, device=dev)
             ch = chain_id.reshape(B * Ln).to(torch.int32).contiguous()
+        xf = x.to(torch.float32).reshape(B * Ln, d)
+        gidx = None
+        if pb.gather is not None:  # non-contiguous ids: tokens of a row sorted by id (packing.pack_sequence_id)
+            gidx = torch.from_numpy(pb.gather).to(dev)
+            xf = xf[gidx]
+            aff, am, ch = (None if t is None else t[gidx].contiguous() for t in (aff, am, ch))
+        else:
+            xf = xf.clone()
         batch = DeviceBatch(pb, dev, aff, am, ch)
-        xf = x.to(torch.float32).reshape(B * Ln, d).clone()
         post, pre, hid = self.engine().forward(xf, batch, want_post=True, want_hiddens=return_hiddens)
-        hiddens = [hid[i].view(B, Ln, d) for i in range(self.n_layers)] if return_hiddens else []
-        return post.view(B, Ln, d), pre.view(B, Ln, d), hiddens
+
+        def back(t):  # packed order -> [B, L, d]
+            if gidx is None:
+                return t.view(B, Ln, d)
+            out = torch.empty_like(t)
+            out[gidx] = t
+            return out.view(B, Ln, d)
+
+        hiddens = [back(hid[i]) for i in range(self.n_layers)] if return_hiddens else []
+        return back(post), back(pre), hiddens

@@ -278,11 +278,34 @@ typedef struct {
     const float* affine; const uint8_t* affine_mask;
     const int32_t* seq_id; const int32_t* chain_id;
     const int32_t* row_cu; int n_rows; int max_row_len;
+    /* 1: the layout of esmk_segments_from_tokens - segments come in (valid prefix, padding) pairs per padded row and
+     * qblk_map holds, per row, blocks (segment 2b, q0) for q0 = 0, 128, ... < L; attention output of padding rows is 0 */
+    int pad_tail;
 } esmk_batch;
 
 size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens);
 int esmk_trunk_forward(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
                        void* workspace, size_t workspace_bytes, esmk_stream_t stream);
+/* Same, capturing ONE block's output only: hidden_layer in [0, n_layers) -> `hiddens` is f32 [M, d] and receives the
+ * output of that block (LogitsConfig.ith_hidden_layer, reference esm/sdk/api.py:397, esm/models/esmc.py:213-218:
+ * the reference stacks all layers and slices; here the other layers are never materialised).  hidden_layer = -1:
+ * all layers, as esmk_trunk_forward. */
+int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, float* x, float* post_norm, float* hiddens,
+                          int hidden_layer, void* workspace, size_t workspace_bytes, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Batch description built ON THE DEVICE for a right-padded [B, L] token matrix, so that the Python forward needs no
+ * host synchronisation.  Replaces `sequence_id = sequence_tokens != pad` + `seqlens = mask.sum(-1)` +
+ * `cu_seqlens = pad(cumsum(seqlens))` (reference esm/models/esmc.py:133-135, esm/layers/attention.py:99-101) for the
+ * padded layout: all B*L positions stay in the packed buffer (n_tokens = B*L is known on the host), row b becomes
+ * segment 2b = its valid prefix and segment 2b+1 = its padding:
+ *     cu_seqlens int32 [2B+1] = {0, len_0, L, L+len_1, 2L, ..., B*L}
+ * mask u8 [B, L] (1 = real token) or NULL (then mask = tokens != pad_id).  Use with esmk_batch.pad_tail = 1.
+ * err_count int32 [1] (optional, device): incremented by the number of tokens outside [0, vocab) and of rows that
+ * are not right-padded (a real token behind a padding position) - the caller reads it when it synchronises anyway.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_segments_from_tokens(const int64_t* tokens, const uint8_t* mask, int B, int L, int64_t pad_id, int vocab,
+                              int32_t* cu_seqlens, int32_t* err_count, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * RegressionHead: logits f32 [M, out_dim].  Replaces Linear -> GELU -> LayerNorm -> Linear

@@ -46,7 +46,7 @@ def test_all_pad_row_and_holes_in_mask(esmc):
     tok = synth.synth_tokens([9, 5, 7], pad_to=12, seed=3)
     tok[1, :] = 1  # a row that is entirely padding
     tok[2, 3] = 1  # a hole inside a sequence: dropped from the segment, rotary position stays the column index
-    out = esmc(tok.cuda())
+    out = esmc(tok.cuda(), drop_pads=True)  # host-described batch: any pad pattern
     ref = oracle_esmc(tok)
     valid = tok != 1
     close(out.embeddings.cpu()[valid], ref["embeddings"][valid])
@@ -70,11 +70,97 @@ def test_int_sequence_id_with_pads_kept(esmc):
     close(out.embeddings.cpu(), ref["embeddings"])  # all positions, pads included
 
 
-def test_token_range_and_noncontiguous_ids_raise(esmc):
+def test_token_range_and_unpadded_rows_are_reported(esmc):
     with pytest.raises(IndexError):
-        esmc(torch.tensor([[0, 70, 2]]).cuda())
-    with pytest.raises(NotImplementedError):
-        esmc(torch.tensor([[0, 5, 6, 2]]).cuda(), sequence_id=torch.tensor([[0, 1, 0, 1]]).cuda())
+        esmc(torch.tensor([[0, 70, 2]]).cuda(), validate=True)
+    # the default path never synchronises, so it cannot raise: bad tokens / rows are counted on the device
+    before = esmc.invalid_token_count()
+    out = esmc(torch.tensor([[0, 70, 2]]).cuda())
+    assert torch.isfinite(out.embeddings).all()
+    assert esmc.invalid_token_count() == before + 1
+    tok = synth.synth_tokens([9, 7], pad_to=12, seed=3)
+    tok[1, 3] = 1  # a hole: this row is not right-padded (drop_pads=True handles it, see above)
+    esmc(tok.cuda())
+    assert esmc.invalid_token_count() == before + 2
+    esmc(synth.synth_tokens([9, 7], pad_to=12, seed=3).cuda())
+    assert esmc.invalid_token_count() == before + 2
+
+
+def test_noncontiguous_sequence_id_general_equality_mask(esmc):
+    """An id that re-appears in a non-adjacent run of its row (attention.py:67 is a plain equality mask): rows are
+    sorted by id on the way in and scattered back on the way out."""
+    tok = synth.synth_tokens([16, 16], seed=21)
+    sid = torch.tensor([[0, 1] * 8, [3] * 5 + [7] * 4 + [3] * 7])
+    out = esmc(tok.cuda(), sequence_id=sid.cuda())
+    ref = oracle_esmc(tok, sid)
+    close(out.embeddings.cpu(), ref["embeddings"])
+    close(out.sequence_logits.cpu(), ref["sequence_logits"])
+    close(out.hidden_states.cpu(), ref["hidden_states"])
+
+
+def test_noncontiguous_sequence_id_through_the_stack_with_geometry():
+    """Same through TransformerStack.forward with a geometric block: frames, masks and chains travel with the tokens."""
+    from esm_amd.affine3d import build_affine3d_from_coordinates
+    from esm_amd.transformer_stack import TransformerStack
+    from oracle import trunk_ref
+    d, H, VH, NL, B, Ln = 128, 2, 8, 2, 2, 24
+    w = synth.make_weights(synth.trunk_shapes("", d, NL, v_heads=VH, n_layers_geom=1), seed=5)
+    m = TransformerStack(d, H, VH, NL, n_layers_geom=1)
+    m.load_state_dict(w)
+    m = m.cuda()
+    x = synth.synth_activations((B, Ln, d), seed=9)
+    coords = synth.synth_backbone(B, Ln, seed=4, nan_frac=0.2)
+    sid = torch.stack([torch.arange(Ln) % 3, (torch.arange(Ln) // 5) % 2])
+    chain = torch.zeros(B, Ln, dtype=torch.int64)
+    chain[0, 13:] = 1
+    aff, mask = build_affine3d_from_coordinates(coords.cuda())
+    post, pre, hid = m(x.cuda(), sid.cuda(), aff, mask, chain.cuda())
+    rpost, rpre, rhid = trunk_ref.transformer_stack(x, sid, w, "", H, NL, v_heads=VH, n_layers_geom=1,
+                                                    frames=trunk_ref.build_frames(coords), chain_id=chain)
+    close(post.cpu(), rpost)
+    close(pre.cpu(), rpre)
+    close(hid[0].cpu(), rhid[0])
+
+
+def test_device_described_batch_equals_host_packed_and_does_not_synchronise(esmc):
+    """The default forward describes the batch on the device (esmk_segments_from_tokens): same results as the
+    host-packed path that drops the pads, zeros at the pads, and no host synchronisation inside the call."""
+    tok = synth.synth_tokens([40, 17, 33, 1], pad_to=40, seed=12).cuda()
+    ref = esmc(tok, drop_pads=True)
+    esmc(tok)  # warm: weight packing, cached batch description
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        out = esmc(tok)
+        lo = esmc.logits(ESMProteinTensor(sequence=tok[1, :17]), LogitsConfig(sequence=True, return_embeddings=True,
+                                                                             return_hidden_states=True, ith_hidden_layer=1))
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    valid = (tok != 1).cpu()
+    close(out.embeddings.cpu()[valid], ref.embeddings.cpu()[valid], 0.01)
+    close(out.sequence_logits.cpu()[valid], ref.sequence_logits.cpu()[valid], 0.01)
+    close(out.hidden_states.cpu()[:, valid], ref.hidden_states.cpu()[:, valid], 0.01)
+    assert out.embeddings.cpu()[~valid].abs().max().item() == 0.0
+    assert out.hidden_states.cpu()[:, ~valid].abs().max().item() == 0.0
+    assert lo.hidden_states.shape == (1, 1, 17, 128)
+    means = {"embedding": True, "hidden": False}
+    esmc(tok, _means=means)
+    want = torch.stack([ref.embeddings[i, :n].mean(dim=0) for i, n in enumerate([40, 17, 33, 1])])
+    close(means["embedding"].cpu(), want.cpu(), 0.01)
+
+
+def test_hidden_layer_selection_is_lazy(esmc):
+    tok = synth.synth_tokens([23, 11], seed=2).cuda()
+    full = esmc(tok)
+    for layer in (0, 2):
+        one = esmc(tok, hidden_layer=layer)
+        assert one.hidden_states.shape == (1, 2, 23, 128)
+        assert torch.equal(one.hidden_states[0], full.hidden_states[layer])
+    neg = esmc.logits(ESMProteinTensor(sequence=tok[0]), LogitsConfig(return_hidden_states=True, ith_hidden_layer=-2))
+    assert torch.equal(neg.hidden_states[0, 0], esmc(tok[:1]).hidden_states[1, 0])
+    with pytest.raises(IndexError):
+        esmc.logits(ESMProteinTensor(sequence=tok[0]), LogitsConfig(return_hidden_states=True, ith_hidden_layer=3))
 
 
 def test_esmc_logits_config_switches(esmc):

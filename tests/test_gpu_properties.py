@@ -113,3 +113,44 @@ def test_full_c2_config_rows_match_oracle():
     small = m(tok[rows].cuda(), return_hidden_states=False)
     c2 = torch.nn.functional.cosine_similarity(small.embeddings.cpu(), emb, dim=-1).min().item()
     assert c2 >= 0.9999, c2
+
+
+@pytest.mark.timeout(240)
+def test_rccl_single_rank_gather_through_dp_runner():
+    """RCCL carries the result gather: a one-rank `nccl` process group (the only one a 1-GPU box can form - RCCL refuses
+    two ranks on one device) runs all_gather_into_tensor and dist.gather on device buffers the way dp.run_data_parallel
+    issues them (side stream, alternating buffers).  Own process: the group is process-global state."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", RANK="0", WORLD_SIZE="1")
+torch.cuda.set_device(0)
+dist.init_process_group("cpu:gloo,cuda:nccl", rank=0, world_size=1)
+dev = torch.device("cuda", 0)
+send = torch.arange(4096 * 64, dtype=torch.float32, device=dev).view(4096, 64).to(torch.bfloat16)
+recv = torch.zeros_like(send)
+side = torch.cuda.Stream()
+side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    dist.all_gather_into_tensor(recv, send)
+torch.cuda.current_stream().wait_stream(side)
+torch.cuda.synchronize()
+assert torch.equal(recv, send)
+out = [torch.zeros_like(send)]
+dist.gather(send, out, dst=0)
+torch.cuda.synchronize()
+assert torch.equal(out[0], send)
+from esm_amd.dp import run_data_parallel
+seqs = [torch.randint(4, 24, (n,)) for n in (50, 20, 64, 33)]
+f = lambda tok, lens: tok.float()[:, None].expand(-1, 8).contiguous()
+res = run_data_parallel(seqs, f, 8, d=64, h=256, token_budget=64, device=dev, wire_dtype=torch.float32)
+assert all(torch.equal(r.cpu(), s.float()[:, None].expand(-1, 8)) for r, s in zip(res, seqs))
+dist.destroy_process_group()
+print("RCCL_OK")
+''' % root
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=200)
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])

@@ -56,9 +56,17 @@ def test_bool_dialect_drop():
     assert np.array_equal(pb.row_cu, [0, 3, 8, 8])
 
 
-def test_non_contiguous_ids_rejected():
-    with pytest.raises(NotImplementedError):
-        pack_sequence_id(np.array([[0, 0, 1, 0]]), 1, 4)
+def test_non_contiguous_ids_sorted_into_segments():
+    """An id that re-appears in a non-adjacent run: the row is stably sorted by id; `gather` is the permutation and
+    positions keep the original columns (attention.py:67 is an equality mask, order inside a segment is irrelevant)."""
+    pb = pack_sequence_id(np.array([[0, 0, 1, 0], [5, 5, 5, 5]]), 2, 4)
+    assert np.array_equal(pb.gather, [0, 1, 3, 2, 4, 5, 6, 7])
+    assert np.array_equal(pb.positions, [0, 1, 3, 2, 0, 1, 2, 3])
+    assert np.array_equal(pb.cu_seqlens, [0, 3, 4, 8])
+    assert np.array_equal(pb.seq_id, [0, 0, 0, 1, 5, 5, 5, 5])
+    assert np.array_equal(pb.row_cu, [0, 4, 8])
+    # contiguous ids stay untouched
+    assert pack_sequence_id(np.array([[0, 0, 1, 1]]), 1, 4).gather is None
 
 
 def test_shape_mismatch():
