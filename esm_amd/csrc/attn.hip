@@ -1,34 +1,64 @@
 // Varlen packed flash attention, head dim 64, non-causal, block-diagonal by segment (cu_seqlens).
 //
 // One workgroup = 4 waves = 128 query rows of one (segment, head); each wave owns 32 query rows.
-// K/V tiles of 64 keys stream through double-buffered LDS (global_load_lds_dwordx4, one barrier per tile).
-// Scores are computed "swapped": S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, so the query row sits on
-// the lane and its keys in the registers: the row max / row sum are register reductions plus ONE exchange
-// with lane^32, and the exponentiated tile converts in place (bf16) into the B operand of
-// O^T += V^T . P^T - no LDS round trip for P.  V^T fragments come from the row-major V tile through
-// ds_read_b64_tr_b16.  q was pre-multiplied by softmax_scale*log2(e) (esmk_qk_prep) so p = exp2(s - m).
+// K/V tiles of 64 keys stream through a small LDS ring by LDS-DMA (buffer_load ... lds: segment base in a scalar
+// descriptor, per-lane byte offsets, the tile offset in an SGPR), one raw s_barrier per tile; four workgroups per CU
+// (128 VGPRs, 32 KiB of LDS) cover each other's waits.
+// Scores are computed "swapped": S^T = K . Q^T with v_mfma_f32_32x32x16_bf16, so the query row sits on the lane and its
+// keys in the registers; the exponentiated tile converts in place (bf16) into the B operand of O^T += V^T . P^T - no
+// LDS round trip for P.  V^T fragments come from the row-major V tile through ds_read_b64_tr_b16.
+//
+// The loop was VALU-issue bound (rocprofv3 PMC, profiles/r02_pmc_attn_before.json: the vector ALU issued 68 % of the
+// kernel's cycles, the MFMA pipe was busy 31 %), so the softmax is arranged to issue as little as possible per tile:
+//   * q was pre-multiplied by softmax_scale*log2(e) (esmk_qk_prep), so p = exp2(s) needs no multiply;
+//   * NO running maximum in the common path: p = exp2(s) is taken straight off the score accumulators.  exp2 and the
+//     fp32 / bf16 formats are scale-free, so p = exp2(s) loses no accuracy against exp2(s - max); what must not happen
+//     is overflow or total underflow, and |s| stays far inside the fp32 exponent range for normalised q / k (QK-LayerNorm:
+//     |s| <= 0.18 |q_h| |k_h|, a few tens).  The guard: after the last tile every row sum must lie in [2^-100, 2^100]
+//     (an inf or NaN fails too).  A block where any row fails is redone from its first tile by a second loop with the
+//     textbook running maximum and per-tile rescale - workgroup-uniform decision, correct for every finite input.
+//     Gone from the common path: the per-tile row maximum (32 max), the subtraction (32), the O rescale (32 mul) and
+//     the cross-half exchange; per tile and wave 32 exp + 32 add + 16 cvt_pk remain beside the 16 MFMAs.
 //
 // LDS images (128-byte rows of 64 bf16): 16-byte chunk index XOR-swizzled,
 //   K: chunk ^ ((row>>1)&7)       -> conflict-free ds_read_b128 row fragments
 //   V: chunk ^ (((row>>1)&1)<<2)  -> conflict-free ds_read_b64_tr_b16 (4 rows x 64 B per half-wave)
 // applied on the DMA source address and on the read address.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
 
 constexpr int QBLK = ESMK_ATTN_QBLK;  // 128 query rows per workgroup
 constexpr int KVBLK = 64;
-constexpr int TILE = KVBLK * 128;  // bytes per K (or V) tile
+constexpr int TILE = KVBLK * 128;     // bytes per K (or V) tile
+constexpr int SLOT = 2 * TILE;        // one ring slot: [K | V]
+#ifndef ESMK_ATTN_NSLOT
+#define ESMK_ATTN_NSLOT 2
+#endif
+#ifndef ESMK_ATTN_SPLITK
+#define ESMK_ATTN_SPLITK 0
+#endif
+#ifndef ESMK_ATTN_MINWG
+#define ESMK_ATTN_MINWG 4
+#endif
+// Measured in one process (tools/attn_ab.py; C2 / C5 / varlen): 2 slots + 4 workgroups per CU (128 VGPRs, 32 KiB) 98.0 /
+// 637 / 287 us; 3 slots + 3 per CU (130 VGPRs, 48 KiB) 103.8 / 655 / 299 us; round-1 kernel 116.7 / 791 / 359 us.
+constexpr int NSLOT = ESMK_ATTN_NSLOT;   // 2: tiles staged one ahead; 3: two ahead with a counted vmcnt, fewer workgroups per CU
+constexpr int LEAD = NSLOT - 1;
+constexpr float L_HI = 1.2676506e30f, L_LO = 7.8886091e-31f;  // 2^100, 2^-100: safe range of a row sum (see the guard)
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
-__global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __restrict__ qkv,
+__global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const __bf16* __restrict__ qkv,
                                                             __bf16* __restrict__ ctx,
                                                             const int* __restrict__ cu_seqlens,
                                                             const int* __restrict__ qblk_map, int n_qblk, int d,
                                                             int H, int nblk, int pad_tail) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE];  // [buf][K | V]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLOT + 16];  // ring + the "redo this block" flag
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int id = xcd_remap(blockIdx.x, nblk);
     const int head = id / n_qblk, qb = id - head * n_qblk;
     const int seg = qblk_map[2 * qb], q0 = qblk_map[2 * qb + 1];
@@ -59,22 +89,30 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
         for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
     }
 
-    // ---- staging: each wave moves 2 K pieces + 2 V pieces (8 rows x 128 B each) per tile ----
-    const int prow = lane >> 3, pchunk = lane & 7;
+    // ---- staging: each wave moves 2 K pieces + 2 V pieces (8 rows x 128 B each) per tile.  Per-lane byte offsets
+    //      from the segment's first K / V row are computed once; the tile offset travels in an SGPR.  The last tile
+    //      has its own offsets with rows clamped to the segment (keys past the end are masked by index below, but
+    //      foreign or NaN rows must never enter the V operand: 0 * NaN = NaN). ----
+    const int nt = (len + KVBLK - 1) / KVBLK;
+    const unsigned ldb = (unsigned)(ld * 2);
     const __bf16* kbase = qkv + (size_t)s0 * ld + d + head * 64;
-    const __bf16* vbase = qkv + (size_t)s0 * ld + 2 * d + head * 64;
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * 2 * TILE;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + d), 0, 0x7fffffff, 0x00020000);
+    const int srow = wave * 16 + (lane >> 3);  // this lane's row inside the tile for piece 0 (piece 1: + 8)
+    const int pchunk = lane & 7;
+    auto stage = [&](int slot_off, int kt) {
+        char* base = smem + slot_off + wave * 2048;
+        const int so = kt * (int)(KVBLK * ldb);
+        // rows of the last tile are clamped to the segment (computed here, once per block, instead of held in registers)
+        const int last_rows = (kt == nt - 1) ? len - (nt - 1) * KVBLK : KVBLK;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int p = wave * 2 + i;
-            const int r = p * 8 + prow;  // row inside the tile
-            int kr = kt * KVBLK + r;
-            kr = kr < len ? kr : len - 1;  // clamp: masked by index below, but never read foreign/NaN rows
-            const int kc = pchunk ^ ((r >> 1) & 7);
-            const int vc = pchunk ^ (((r >> 1) & 1) << 2);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(kbase + (size_t)kr * ld + kc * 8), LDS_PTR(base + p * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds(GLB_PTR(vbase + (size_t)kr * ld + vc * 8), LDS_PTR(base + TILE + p * 1024), 16, 0, 0);
+            const int r = srow + 8 * i;
+            const int rl = r < last_rows ? r : last_rows - 1;
+            const unsigned kc = (unsigned)(pchunk ^ ((r >> 1) & 7)) * 16u;
+            const unsigned vc = (unsigned)(pchunk ^ (((r >> 1) & 1) << 2)) * 16u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rK, LDS_PTR(base + i * 1024), 16, (int)((unsigned)rl * ldb + kc), so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(base + TILE + i * 1024), 16, (int)((unsigned)rl * ldb + vc), so, 0, 0);
         }
     };
 
@@ -101,91 +139,206 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
 
     f32x16 o[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
+    for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+    float lsum = 0.f;    // this half-wave's part of the row sum
 
-    const int nt = (len + KVBLK - 1) / KVBLK;
-    stage(0, 0);
-    for (int kt = 0; kt < nt; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < nt) stage((kt + 1) & 1, kt + 1);
-        const char* kt_ = smem + (kt & 1) * 2 * TILE;
-        const char* vt_ = kt_ + TILE;
-
-        // ---- S^T = K . Q^T ----
-        f32x16 s[2];
+    // S^T = K . Q^T for the 64 keys of the tile at kt_
+    auto scores = [&](const char* kt_, f32x16 (&s)[2]) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
+            bf16x8 kf[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[mt][r] = 0.f;
+            for (int ks = 0; ks < 4; ++ks) kf[ks] = *(const bf16x8*)(kt_ + (koff[mt] ^ (ks << 5)));
+            f32x16 z;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 kf = *(const bf16x8*)(kt_ + (koff[mt] ^ (ks << 5)));
-                s[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s[mt], 0, 0, 0);
-            }
+            for (int r = 0; r < 16; ++r) z[r] = 0.f;
+            s[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0], z, 0, 0, 0);
+#pragma unroll
+            for (int ks = 1; ks < 4; ++ks) s[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[ks], qf[ks], s[mt], 0, 0, 0);
+            if (ESMK_ATTN_SPLITK && mt == 0) __builtin_amdgcn_sched_barrier(0);  // at most one half's K fragments live
         }
-        // ---- mask keys beyond the segment (last tile only) ----
-        const int kleft = len - kt * KVBLK;
-        if (kleft < KVBLK) {
+    };
+    auto mask_tail = [&](f32x16 (&s)[2], int kleft) {  // keys beyond the segment (last tile only)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (mt * 32 + crow(r, hi) >= kleft) s[mt][r] = -INFINITY;
-        }
-        // ---- online softmax (row = lane&31, its keys are spread over 32 registers x 2 half-waves) ----
-        float mx = s[0][0];
+            for (int r = 0; r < 16; ++r)
+                if (mt * 32 + crow(r, hi) >= kleft) s[mt][r] = -INFINITY;
+    };
+
+    // V^T fragments are read by inline asm: hipcc treats the ds_read_tr builtin as a reader of the LDS-DMA destination
+    // and drains the whole DMA queue (s_waitcnt vmcnt(0)) in front of the first one of every tile, which would
+    // serialise the ring.  Form: "=v" loads, later a wait statement naming every destination "+v" and a
+    // sched_barrier(0) before the consuming MFMAs (cdna_hip_programming.md 5.7 item 1 (ii), rule 18).
+    // Two register sets alternate over the four 16-key steps, so the reads of step sp+1 fly under the MFMAs of sp.
+    const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+    unsigned va[2][2];  // [read e][dh tile t] byte offsets inside a V tile (key step 0)
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+    for (int e = 0; e < 2; ++e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        const float mnew = fmaxf(m, mx);  // finite: every tile holds at least one unmasked key
-        const float alpha = __builtin_amdgcn_exp2f(m - mnew);
-        m = mnew;
+        for (int t = 0; t < 2; ++t) va[e][t] = (unsigned)(voff[e] ^ (t << 6));
+    struct VFrag { u32x2 a0, a1, b0, b1; };  // t = 0: (a0, a1), t = 1: (b0, b1)
+#define VREAD(F, BASE, SP)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%c8\n\tds_read_b64_tr_b16 %1, %5 offset:%c8\n\t"       \
+                 "ds_read_b64_tr_b16 %2, %6 offset:%c8\n\tds_read_b64_tr_b16 %3, %7 offset:%c8"            \
+                 : "=v"(F.a0), "=v"(F.a1), "=v"(F.b0), "=v"(F.b1)                                        \
+                 : "v"(BASE + va[0][0]), "v"(BASE + va[1][0]), "v"(BASE + va[0][1]), "v"(BASE + va[1][1]), \
+                   "i"((SP) * 2048)                                                                      \
+                 : "memory")
+#define VWAIT(F, N)                                                                                     \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(F.a0), "+v"(F.a1), "+v"(F.b0), "+v"(F.b1)::"memory"); \
+    __builtin_amdgcn_sched_barrier(0)
+    // k-step SP covers keys 16sp..16sp+15 = registers 8(sp&1).. of s[sp>>1]
+    // (keys +16sp -> +2048sp bytes: 16 rows; row bits >= 4 do not touch either swizzle)
+#define PV_STEP(F, SP)                                                                                  \
+    {                                                                                                   \
+        bf16x8 pf;                                                                                      \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[(SP) >> 1][8 * ((SP) & 1) + j]; \
+        const u32x4 v0 = {F.a0.x, F.a0.y, F.a1.x, F.a1.y}, v1 = {F.b0.x, F.b0.y, F.b1.x, F.b1.y};       \
+        o[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v0), pf, o[0], 0, 0, 0); \
+        o[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, v1), pf, o[1], 0, 0, 0); \
+    }
+    // O^T += V^T . P^T for the tile whose first V read (step 0 -> fa) is already in flight
+#define PV_ALL()                                   \
+    __builtin_amdgcn_sched_barrier(0);             \
+    VREAD(fb, vbase, 1);                           \
+    VWAIT(fa, 4);                                  \
+    PV_STEP(fa, 0)                                 \
+    __builtin_amdgcn_sched_barrier(0);             \
+    VREAD(fa, vbase, 2);                           \
+    VWAIT(fb, 4);                                  \
+    PV_STEP(fb, 1)                                 \
+    __builtin_amdgcn_sched_barrier(0);             \
+    VREAD(fb, vbase, 3);                           \
+    VWAIT(fa, 4);                                  \
+    PV_STEP(fa, 2)                                 \
+    __builtin_amdgcn_sched_barrier(0);             \
+    VWAIT(fb, 0);                                  \
+    PV_STEP(fb, 3)
+
+    // One 64-key tile of the common path.  MASKED (compile-time: as a run-time condition hipcc if-converts the mask
+    // into ~90 compares and selects that every tile would execute): the segment's last tile when it holds keys past
+    // the end, which get -inf scores.
+    auto tile = [&](auto masked_tag, int kt, int cur) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const char* kt_ = smem + cur;
+        const unsigned vbase = lds0 + (unsigned)cur + TILE;
+        f32x16 s[2];
+        scores(kt_, s);
+        VFrag fa, fb;
+        VREAD(fa, vbase, 0);
+        if (MASKED) mask_tail(s, len - kt * KVBLK);
         float ps = 0.f;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float p = __builtin_amdgcn_exp2f(s[mt][r] - mnew);
+                const float p = __builtin_amdgcn_exp2f(s[mt][r]);
                 s[mt][r] = p;
                 ps += p;
             }
-        lsum = lsum * alpha + ps;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+        lsum += ps;
+        PV_ALL();
+    };
 
-        // ---- O^T += V^T . P^T : k-step sp covers keys 16sp..16sp+15 = registers 8(sp&1).. of s[sp>>1] ----
-#pragma unroll
-        for (int sp = 0; sp < 4; ++sp) {
-            bf16x8 pf;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[sp >> 1][8 * (sp & 1) + j];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                // keys +16sp -> +2048sp bytes (16 rows; row bits >= 4 do not touch either swizzle);
-                // dh tile t -> logical chunk + 4t  (XOR with 4<<4 = 64)
-                const char* vb = vt_ + sp * 2048;
-                const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + (voff[0] ^ (t << 6))));
-                const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(vb + (voff[1] ^ (t << 6))));
-                const s16x8 vv = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
-                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vv), pf, o[t], 0, 0, 0);
-            }
+    int* redo_flag = (int*)(smem + NSLOT * SLOT);
+    if (tid == 0) *redo_flag = 0;  // ordered before any later write by the barriers of the loop
+    const bool ragged = (len & (KVBLK - 1)) != 0;  // the last tile holds keys past the end
+    stage(0, 0);
+    if (LEAD > 1 && nt > 1) stage(SLOT, 1);
+    {
+        int cur = 0;           // byte offset of the ring slot holding tile kt
+        int nxt = LEAD * SLOT; // slot that receives tile kt + LEAD (afterwards: the one read a tile ago)
+        int kt = 0;
+        const int n_plain = ragged ? nt - 1 : nt;  // tiles [0, n_plain) hold no key past the end
+        for (; kt < n_plain; ++kt) {
+            // tile kt has landed (this wave's pieces); the pieces of later tiles may stay in flight
+            if (kt + 1 < nt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (LEAD - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... for every wave; and every wave is done reading the slot refilled next
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + LEAD < nt) stage(nxt, kt + LEAD);
+            tile(std::false_type{}, kt, cur);
+            nxt = cur;
+            cur = cur + SLOT == NSLOT * SLOT ? 0 : cur + SLOT;
+        }
+        if (ragged) {  // the segment's last tile holds keys past the end
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            tile(std::true_type{}, kt, cur);
         }
     }
 
-    // ---- epilogue: O^T[dh = 32t + crow(r,hi)][q = l31] / l ----
+    // ---- guarded loop: only when some row sum of the block left the safe range above (scores beyond about +-100 in
+    //      log2 units, or a NaN / inf came in).  The whole block is redone with the running row maximum and a rescale
+    //      per tile.  Workgroup-uniform (the loop has barriers): OR over the waves via LDS. ----
+    {
+        const float ltot = lsum + __shfl_xor(lsum, 32);
+        const int lane_g = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const bool bad = !(ltot > L_LO && ltot < L_HI) && (q0 + wave * 32 + (lane_g & 31) < len);  // !(..): inf / NaN too
+        if (__any(bad) && lane == 0) *redo_flag = 1;
+        __syncthreads();  // also: every wave is done with the ring
+        const bool redo = *redo_flag != 0;
+        if (__builtin_expect(redo, 0)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[0][r] = o[1][r] = 0.f;
+            lsum = 0.f;
+            float m = -INFINITY;
+            stage(0, 0);
+            for (int kt = 0; kt < nt; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                const int cur = (kt & 1) * SLOT;
+                if (kt + 1 < nt) stage(SLOT - cur, kt + 1);
+                const char* kt_ = smem + cur;
+                const unsigned vbase = lds0 + (unsigned)cur + TILE;
+                f32x16 s[2];
+                scores(kt_, s);
+                VFrag fa, fb;
+                VREAD(fa, vbase, 0);
+                if (kt == nt - 1) mask_tail(s, len - kt * KVBLK);
+                float mx = s[0][0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[0][r]);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[1][r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
+                const float mnew = fmaxf(m, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m - mnew);
+                m = mnew;
+                float ps = 0.f;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float p = __builtin_amdgcn_exp2f(s[mt][r] - mnew);
+                        s[mt][r] = p;
+                        ps += p;
+                    }
+                lsum = lsum * alpha + ps;
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) o[t][r] *= alpha;
+                PV_ALL();
+            }
+        }
+    }
+#undef PV_ALL
+#undef PV_STEP
+#undef VWAIT
+#undef VREAD
+
+    // ---- epilogue: O^T[dh = 32t + crow(r,hi)][q = l31] / l.  The lane's position is re-derived here (v_mbcnt) rather
+    //      than kept alive through the loop: the kernel sits exactly at the 128-VGPR budget of four workgroups per CU ----
     lsum += __shfl_xor(lsum, 32);
     const float inv = 1.0f / lsum;
-    const int qr = q0 + wave * 32 + l31;
+    const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int l31e = lane_e & 31, hie = lane_e >> 5;
+    const int qr = q0 + wave * 32 + l31e;
     if (qr >= len && qr < tail_end) {
-        u32x4* zp = (u32x4*)(ctx + (size_t)(s0 + qr) * d + head * 64 + hi * 32);
+        u32x4* zp = (u32x4*)(ctx + (size_t)(s0 + qr) * d + head * 64 + hie * 32);
 #pragma unroll
         for (int i = 0; i < 4; ++i) zp[i] = u32x4{0u, 0u, 0u, 0u};
     }
@@ -198,7 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_varlen_kernel(const __bf16* __res
                 u32x2 pk;
                 pk.x = pack_bf16x2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv);
                 pk.y = pack_bf16x2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
-                *(u32x2*)(op + 32 * t + 8 * g + 4 * hi) = pk;
+                *(u32x2*)(op + 32 * t + 8 * g + 4 * hie) = pk;
             }
     }
 }

@@ -114,16 +114,26 @@ def test_noncontiguous_sequence_id_through_the_stack_with_geometry():
     chain = torch.zeros(B, Ln, dtype=torch.int64)
     chain[0, 13:] = 1
     aff, mask = build_affine3d_from_coordinates(coords.cuda())
-    post, pre, hid = m(x.cuda(), sid.cuda(), aff, mask, chain.cuda())
-    rpost, rpre, rhid = trunk_ref.transformer_stack(x, sid, w, "", H, NL, v_heads=VH, n_layers_geom=1,
-                                                    frames=trunk_ref.build_frames(coords), chain_id=chain)
-    # gate of the other geometric-stack tests (test_gpu_models.emb_ok): with 2 layers the residual scale is
-    # sqrt(2/36), which multiplies the geometric block's bf16 rounding by 4.2 - a max-abs bound on raw N(0,1) inputs
-    # is not meaningful here (the same inputs with contiguous ids show the same deviations)
-    for a, b in ((post.cpu(), rpost), (pre.cpu(), rpre), (hid[0].cpu(), rhid[0])):
-        cos = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1).min().item()
-        assert cos >= 0.999, cos
-        assert (a - b).norm().item() <= 0.03 * b.norm().item()
+    frames = trunk_ref.build_frames(coords)
+
+    def run(ids):
+        post, pre, hid = m(x.cuda(), ids.cuda(), aff, mask, chain.cuda())
+        rpost, rpre, rhid = trunk_ref.transformer_stack(x, ids, w, "", H, NL, v_heads=VH, n_layers_geom=1, frames=frames,
+                                                        chain_id=chain)
+        out = []
+        for a, b in ((post.cpu(), rpost), (pre.cpu(), rpre), (hid[0].cpu(), rhid[0])):
+            cos = torch.nn.functional.cosine_similarity(a.double(), b.double(), dim=-1).min().item()
+            out.append((cos, (a - b).norm().item() / b.norm().item()))
+        return out
+
+    # With 2 layers the residual scale is sqrt(2/36): the geometric block's bf16 rounding enters the stream times 4.2, on
+    # raw N(0,1) inputs - so the yardstick is the SAME model and inputs with contiguous ids (the path every fixture
+    # covers): sorting rows by id must not cost accuracy beyond that.
+    contig = run(torch.stack([torch.arange(Ln) // 8, torch.arange(Ln) // 12]))
+    scattered = run(sid)
+    for (c0, r0), (c1, r1) in zip(contig, scattered):
+        assert c1 >= 0.995 and c1 >= c0 - 0.002, (c0, c1)
+        assert r1 <= 0.03 and r1 <= 1.5 * r0 + 1e-3, (r0, r1)
 
 
 def test_device_described_batch_equals_host_packed_and_does_not_synchronise(esmc):

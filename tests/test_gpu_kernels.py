@@ -215,6 +215,79 @@ def test_qk_prep_and_attention(lens, H):
     assert err <= 0.03 * max(1.0, ref.abs().max().item()), err
 
 
+def _attn_direct(q, k, v, lens):
+    """esmk_attn_varlen on ready-made q (already scaled by log2 e / 8), k, v [N, H, 64] bf16 -> ctx [N, H*64] fp32 (cpu)."""
+    L, lib, _ = _env()
+    from esm_amd.packing import pack_lengths
+    N, H, _ = q.shape
+    d = 64 * H
+    pb = pack_lengths(lens)
+    qkv = torch.cat([q.reshape(N, d), k.reshape(N, d), v.reshape(N, d)], dim=1).contiguous().cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
+    cu, qmap = dev(pb.cu_seqlens), dev(pb.qblk_map.reshape(-1))
+    ctx = torch.full((N, d), float("nan"), dtype=torch.bfloat16, device="cuda")
+    L.check(lib.esmk_attn_varlen(qkv.data_ptr(), ctx.data_ptr(), cu.data_ptr(), qmap.data_ptr(), pb.qblk_map.shape[0],
+                                 N, d, H, _s()))
+    torch.cuda.synchronize()
+    return ctx.float().cpu()
+
+
+def _attn_direct_ref(q, k, v, lens):
+    """fp64 softmax(q.k^T * ln 2) . v per segment (q carries log2 e, the kernel exponentiates with exp2)."""
+    out, a = [], 0
+    for n in lens:
+        qs, ks, vs = (t[a:a + n].double().transpose(0, 1) for t in (q, k, v))  # [H, n, 64]
+        sc = qs @ ks.transpose(1, 2) * math.log(2.0)
+        out.append((torch.softmax(sc, dim=-1) @ vs).transpose(0, 1).reshape(n, -1))
+        a += n
+    return torch.cat(out).float()
+
+
+@pytest.mark.parametrize("profile", ["jump_late", "jump_mid_then_flat", "ramp_up", "ramp_down", "huge_first_tile"])
+def test_attention_score_range_paths(profile):
+    """The attention kernel keeps the first key tile's row maximum as its reference and redoes a block with the textbook
+    running maximum when a row sum leaves the safe range.  Rule: a rare data-dependent path needs inputs that FORCE it
+    and a full independent reference (fp64 here).  Scores are built as q = e_0 * a_i, k = e_0 * b_j, so s_ij = a_i b_j."""
+    H, lens = 2, [300, 64, 700, 1]
+    N = sum(lens)
+    g = torch.Generator().manual_seed(5)
+    q = (0.05 * torch.randn(N, H, 64, generator=g))
+    k = (0.05 * torch.randn(N, H, 64, generator=g))
+    v = torch.randn(N, H, 64, generator=g)
+    pos = torch.cat([torch.arange(n) for n in lens]).float()
+    q[:, :, 0] = 1.0
+    if profile == "jump_late":          # one key far above everything else, beyond the first tile: exp2(250) overflows fp32
+        b = torch.where(pos == 200, 250.0, 0.0)
+    elif profile == "jump_mid_then_flat":  # the jump sits in tile 2 of the long segments, flat (but lower) scores follow
+        b = torch.where((pos >= 130) & (pos < 135), 180.0, torch.where(pos > 400, 100.0, -3.0))
+    elif profile == "ramp_up":          # maximum grows steadily: +0.15 per key, 100 over a 700-key segment (no overflow: p <= 2^100)
+        b = 0.13 * pos
+    elif profile == "ramp_down":        # first tile holds the maximum: everything later underflows towards 0
+        b = -0.5 * pos
+    else:                               # first tile far BELOW the rest
+        b = torch.where(pos < 64, -300.0, 5.0)
+    k[:, :, 0] = b[:, None]
+    q, k, v = q.bfloat16(), k.bfloat16(), v.bfloat16()
+    got = _attn_direct(q, k, v, lens)
+    ref = _attn_direct_ref(q.float(), k.float(), v.float(), lens)
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 0.02 * max(1.0, ref.abs().max().item()), (profile, err)
+
+
+def test_attention_nan_input_stays_local():
+    """A NaN in one sequence's keys makes that sequence's rows NaN and nothing else (the guarded path must terminate)."""
+    H, lens = 1, [200, 130]
+    N = sum(lens)
+    g = torch.Generator().manual_seed(6)
+    q, k, v = (torch.randn(N, H, 64, generator=g) * s for s in (0.2, 1.0, 1.0))
+    k[150, 0, 3] = float("nan")
+    got = _attn_direct(q.bfloat16(), k.bfloat16(), v.bfloat16(), lens)
+    assert torch.isnan(got[:200]).all()
+    ref = _attn_direct_ref(q.bfloat16().float()[200:], k.bfloat16().float()[200:], v.bfloat16().float()[200:], [130])
+    assert (got[200:] - ref).abs().max().item() <= 0.02 * max(1.0, ref.abs().max().item())
+
+
 def test_attn_plan_matches_host_logic():
     L, lib, _ = _env()
     from esm_amd.packing import plan_attention

@@ -11,7 +11,11 @@ from esm_amd.packing import pack_lengths
 
 lib = L.lib()
 st = torch.cuda.current_stream().cuda_stream
+ONLY = sys.argv[1] if len(sys.argv) > 1 else None   # "c2" / "c5" / "varlen": one shape only (PMC passes)
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for name, lens, H in (("c2 64x512 H18", [512] * 64, 18), ("c5 4x4096 H40", [4096] * 4, 40), ("varlen H18", list(np.random.default_rng(0).integers(64, 2048, 40)), 18)):
+    if ONLY and not name.startswith(ONLY):
+        continue
     d = 64 * H
     pb = pack_lengths(lens)
     N = pb.n_tokens
@@ -32,10 +36,10 @@ for name, lens, H in (("c2 64x512 H18", [512] * 64, 18), ("c5 4x4096 H40", [4096
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(20):
+        for _ in range(ITERS):
             fn()
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 20
+        ms = e0.elapsed_time(e1) / ITERS
         extra = f"{fl/ms/1e9:8.1f} TF/s" if fl else f"{N*2*d*2*2/ms/1e6:8.1f} GB/s"
         print(f"{name:16s} {nm:10s} {ms*1e3:8.1f} us {extra}", flush=True)
