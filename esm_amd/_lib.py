@@ -63,6 +63,7 @@ SIGNATURES = {
     "esmk_gemm_ws": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, C.c_size_t, vp]),
     "esmk_gemm_noalloc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+    "esmk_qk_prep_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),
     "esmk_attn_varlen": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_attn_l64_d128": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

@@ -160,7 +160,8 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 // LN = false (qk_layernorm=False block variant, attention.py:34-38): rotary and the q scale only.
 template <int NU, bool LN = true>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
 __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
-                                                      const float* __restrict__ gk,
+                                                      const float* __restrict__ gk, const float* __restrict__ bq,
+                                                      const float* __restrict__ bk,
                                                       const int* __restrict__ positions,
                                                       const float* __restrict__ rcos,
                                                       const float* __restrict__ rsin, int rope_len, int M, int d,
@@ -246,15 +247,22 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
             const bool isk = kw[u] != 0.f;
             const float rs = isk ? rstd_k : rstd_q;
             f32x4 ga = f32x4{rs, rs, rs, rs}, gb = ga;
+            f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bb = ba;  // biased q_ln / k_ln (bias=True blocks): beta, q's scaled like q
             if constexpr (LN) {
                 const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
                 ga = *(const f32x4*)g * rs;
                 gb = *(const f32x4*)(g + 4) * rs;
+                if (bq) {  // kernel argument: uniform
+                    const float* b = (isk ? bk - units_half * 8 : bq) + uoff[u];
+                    const float bs = isk ? 1.0f : q_scale;
+                    ba = *(const f32x4*)b * bs;
+                    bb = *(const f32x4*)(b + 4) * bs;
+                }
             }
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]);
+                const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]) + (e < 4 ? ba[e & 3] : bb[e & 3]);
                 const float pn = __shfl_xor(n, 4);
                 o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
             }
@@ -424,10 +432,18 @@ extern "C" int esmk_add2_layernorm(float* x, const void* delta_a, const void* de
 extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const int32_t* positions, const float* rcos,
                             const float* rsin, int rope_len, int M, int d, int H, float q_scale, float eps,
                             esmk_stream_t stream) {
+    return esmk_qk_prep_ex(qkv, gq, gk, nullptr, nullptr, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps, stream);
+}
+
+extern "C" int esmk_qk_prep_ex(void* qkv, const float* gq, const float* gk, const float* bq, const float* bk,
+                               const int32_t* positions, const float* rcos, const float* rsin, int rope_len, int M,
+                               int d, int H, float q_scale, float eps, esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;
     if (!qkv || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: null pointer");
     if ((gq == nullptr) != (gk == nullptr))
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: gamma_q and gamma_k must both be given (QK-LayerNorm) or both be NULL");
+    if ((bq == nullptr) != (bk == nullptr) || (bq && !gq))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_qk_prep: beta_q and beta_k go together and need the gammas");
     const bool ln = gq != nullptr;
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_qk_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
     const int nu = (16 * H + 63) / 64;
@@ -443,10 +459,10 @@ extern "C" int esmk_qk_prep(void* qkv, const float* gq, const float* gk, const i
         if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
         if (ln)                                                                                                \
             hipLaunchKernelGGL((qk_prep_kernel<NU, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, \
-                               gk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                    \
+                               gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);            \
         else                                                                                                   \
             hipLaunchKernelGGL((qk_prep_kernel<NU, false>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, \
-                               gq, gk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);                \
+                               gq, gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);        \
     } while (0)
     switch (nu) {
         case 1: QK_LAUNCH(1); break;

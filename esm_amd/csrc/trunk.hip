@@ -195,12 +195,15 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
 }
 
 static size_t head_splitk_bytes(int M, int d) {
-    // out_dim is not known to the size query: 4096 covers the widest head of the path (ESM3 structure head is 4096,
-    // function 2080); wider heads simply run unsplit
-    size_t a = esmk_gemm_workspace_bytes(M, d, d), b = 0;
-    const int outs[] = {64, 11, 19, 1478, 2080, 4096};
-    for (int o : outs) { const size_t x = esmk_gemm_workspace_bytes(M, o, d); if (x > b) b = x; }
-    return a > b ? a : b;
+    // out_dim is not known to the size query: take the largest split-K need over every output width (the need is 0
+    // again once a width has enough tiles to fill the chip unsplit, so the scan is short and bounded by ~25 MB)
+    size_t best = esmk_gemm_workspace_bytes(M, d, d);
+    for (int n = 128; n <= 65536; n += 128) {
+        const size_t x = esmk_gemm_workspace_bytes(M, n, d);
+        if (x > best) best = x;
+        if (x == 0 && n > 4096) break;
+    }
+    return best;
 }
 
 extern "C" size_t esmk_head_workspace_bytes(int n_tokens, int d_model) {

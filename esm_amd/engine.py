@@ -237,8 +237,6 @@ class VariantEngine:
                  bias: bool = False, qk_layernorm: bool = True, ffn_type: str = "swiglu"):
         if d_model != 64 * n_heads:
             raise L.EsmkError(f"head dim must be 64 (d_model={d_model}, n_heads={n_heads})")
-        if bias and qk_layernorm:
-            raise L.EsmkError("biased q_ln / k_ln (bias=True with qk_layernorm=True) is not built")
         self.lib = L.lib()
         self.device = dev = torch.device(device)
         self.d, self.H, self.n_layers, self.Hv = d_model, n_heads, n_layers, v_heads or 0
@@ -260,6 +258,8 @@ class VariantEngine:
                       b_qkv=ob(b + "attn.layernorm_qkv.1.bias"),
                       gq=f(b + "attn.q_ln.weight") if qk_layernorm else None,
                       gk=f(b + "attn.k_ln.weight") if qk_layernorm else None,
+                      bq=ob(b + "attn.q_ln.bias") if qk_layernorm else None,  # bias=True: biased q_ln / k_ln
+                      bk=ob(b + "attn.k_ln.bias") if qk_layernorm else None,
                       w_o=pack_weight(weights[prefix + b + "attn.out_proj.weight"], dev), b_o=ob(b + "attn.out_proj.bias"),
                       ln2_g=f(b + "ffn.0.weight"), ln2_b=f(b + "ffn.0.bias"),
                       w1=pack_weight(weights[prefix + b + "ffn.1.weight"], dev,
@@ -304,8 +304,9 @@ class VariantEngine:
         for i, ly in enumerate(self.layers):
             ln(ly["ln1_g"], ly["ln1_b"])
             gemm(xb, d, ly["w_qkv"], 3 * d, d, L.EPI_BF16, ly["b_qkv"], 1.0, qkv)
-            L.check(lib.esmk_qk_prep(L.ptr(qkv), L.ptr(ly["gq"]), L.ptr(ly["gk"]), L.ptr(batch.positions), L.ptr(self._cos),
-                                     L.ptr(self._sin), self.rope_len, N, d, H, q_scale, 1e-5, s), "esmk_qk_prep")
+            L.check(lib.esmk_qk_prep_ex(L.ptr(qkv), L.ptr(ly["gq"]), L.ptr(ly["gk"]), L.ptr(ly["bq"]), L.ptr(ly["bk"]),
+                                        L.ptr(batch.positions), L.ptr(self._cos), L.ptr(self._sin), self.rope_len, N, d, H,
+                                        q_scale, 1e-5, s), "esmk_qk_prep")
             L.check(lib.esmk_attn_varlen(L.ptr(qkv), L.ptr(ctx), L.ptr(batch.cu_seqlens), L.ptr(batch.qblk_map),
                                          batch.desc.n_qblk, N, d, H, s), "esmk_attn_varlen")
             gemm(ctx, d, ly["w_o"], d, d, L.EPI_RESIDUAL, ly["b_o"], self.inv_s, x)

@@ -65,17 +65,14 @@ class TransformerStack(nn.Module):
     """Every constructor option of the reference (transformer_stack.py:26-62).  The ESM C / ESM3 variant (bias=False,
     qk_layernorm=True, ffn_type="swiglu", geometric blocks with mask_and_zero_frameless=True) runs as ONE C call
     (`esmk_trunk_forward`, fused residual deltas); the other block variants of blocks.py:73-115 run block by block over
-    the same kernels (`engine.VariantEngine`).  Not built: bias=True together with qk_layernorm=True (q_ln / k_ln
-    would then carry a bias, attention.py:32-33; no model of the reference uses that combination)."""
+    the same kernels (`engine.VariantEngine`), bias=True together with qk_layernorm=True included (q_ln / k_ln then
+    carry a bias, attention.py:32-33: `esmk_qk_prep_ex`)."""
 
     def __init__(self, d_model: int, n_heads: int, v_heads: int | None, n_layers: int, n_layers_geom: int = 1,
                  scale_residue: bool = True, mask_and_zero_frameless: bool = False, bias: bool = False,
                  qk_layernorm: bool = True, ffn_type: str = "swiglu", expansion_ratio: float = 8 / 3,
                  use_flash_attn: bool = False):
         super().__init__()
-        if bias and qk_layernorm:
-            raise NotImplementedError("bias=True with qk_layernorm=True (biased q_ln / k_ln) is not built: no model of "
-                                      "the reference uses it")
         if ffn_type not in ("swiglu", "gelu"):
             raise ValueError(f"Unknown ffn_type: {ffn_type}")
         if n_layers_geom > 0 and v_heads is None:

@@ -150,6 +150,12 @@ int esmk_gemm_noalloc(const void* A_bf16, int lda, const void* W_packed, int M, 
 int esmk_qk_prep(void* qkv_bf16, const float* gamma_q, const float* gamma_k, const int32_t* positions,
                  const float* rope_cos, const float* rope_sin, int rope_len, int M, int d, int n_heads,
                  float q_scale, float eps, esmk_stream_t stream);
+/* Same with biased q_ln / k_ln: the bias=True block variant keeps QK-LayerNorm as nn.LayerNorm(d_model, bias=True)
+ * (reference attention.py:31-33 with blocks.py:81).  beta_q / beta_k f32 [d], both or neither (NULL = esmk_qk_prep);
+ * q's beta is scaled by q_scale like the rest of q. */
+int esmk_qk_prep_ex(void* qkv_bf16, const float* gamma_q, const float* gamma_k, const float* beta_q,
+                    const float* beta_k, const int32_t* positions, const float* rope_cos, const float* rope_sin,
+                    int rope_len, int M, int d, int n_heads, float q_scale, float eps, esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Varlen packed flash attention (non-causal, block-diagonal by segment), head dim 64.

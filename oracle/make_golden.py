@@ -149,6 +149,7 @@ STACK_VARIANTS = {  # name -> (d, H, NL, L, wseed, VH, constructor options)
     "stackvar_gelu_noscale": (192, 3, 2, 33, 83, None, dict(n_layers_geom=0, ffn_type="gelu", expansion_ratio=2.0,
                                                             scale_residue=False)),
     "stackvar_geom_nozero": (128, 2, 2, 40, 84, 8, dict(n_layers_geom=1, mask_and_zero_frameless=False)),
+    "stackvar_bias_qkln": (128, 2, 2, 40, 86, None, dict(n_layers_geom=0, bias=True, qk_layernorm=True)),
     "stackvar_bias_geom2": (128, 2, 2, 40, 85, 8, dict(n_layers_geom=2, bias=True, qk_layernorm=False, ffn_type="gelu",
                                                         expansion_ratio=4.0, mask_and_zero_frameless=True)),
 }

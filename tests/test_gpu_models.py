@@ -67,7 +67,7 @@ def test_stack_vs_golden(name):
     assert len(hid) == int(fx["NL"])
 
 
-@pytest.mark.parametrize("name", ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale",
+@pytest.mark.parametrize("name", ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale", "stackvar_bias_qkln",
                                   "stackvar_geom_nozero", "stackvar_bias_geom2"])
 def test_stack_variants_vs_golden(name):
     """The generic TransformerStack with the reference's other constructor options (bias, qk_layernorm=False, GELU FFN,
@@ -91,10 +91,9 @@ def test_stack_variants_vs_golden(name):
     assert len(hid) == int(fx["NL"])
 
 
-def test_stack_variant_not_built():
+def test_stack_variant_bad_options():
     from esm_amd.transformer_stack import TransformerStack
-    with pytest.raises(NotImplementedError):
-        TransformerStack(128, 2, None, 2, n_layers_geom=0, bias=True, qk_layernorm=True)
+    assert not TransformerStack(128, 2, None, 2, n_layers_geom=0, bias=True, qk_layernorm=True).fused
     with pytest.raises(ValueError):
         TransformerStack(128, 2, None, 2, n_layers_geom=0, ffn_type="relu")
 

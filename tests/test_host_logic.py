@@ -144,8 +144,8 @@ def test_block_variants_state_dict_and_rejections():
     assert m.state_dict()["blocks.0.ffn.1.weight"].shape == (512, 128)
     assert TransformerStack(128, 2, 8, 2, n_layers_geom=1, mask_and_zero_frameless=True).fused
     assert TransformerStack(128, 2, None, 2, n_layers_geom=0).fused
-    with pytest.raises(NotImplementedError):
-        TransformerStack(128, 2, None, 1, n_layers_geom=0, bias=True)  # biased q_ln / k_ln
+    biased = TransformerStack(128, 2, None, 1, n_layers_geom=0, bias=True)  # biased q_ln / k_ln (attention.py:32-33)
+    assert "blocks.0.attn.q_ln.bias" in biased.state_dict() and not biased.fused
     with pytest.raises(ValueError):
         TransformerStack(128, 2, None, 1, n_layers_geom=0, ffn_type="relu")
     with pytest.raises(ValueError):

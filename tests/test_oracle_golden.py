@@ -44,7 +44,7 @@ def test_stack(name):
     _close(pre[:, ::s][valid], G.t(fx["pre"])[valid])
 
 
-STACK_VARIANTS = ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale", "stackvar_geom_nozero",
+STACK_VARIANTS = ["stackvar_bias_noqkln_gelu", "stackvar_noqkln_swiglu", "stackvar_gelu_noscale", "stackvar_bias_qkln", "stackvar_geom_nozero",
                   "stackvar_bias_geom2"]
 
 
