@@ -141,13 +141,15 @@ def test_device_described_batch_equals_host_packed_and_does_not_synchronise(esmc
     host-packed path that drops the pads, zeros at the pads, and no host synchronisation inside the call."""
     tok = synth.synth_tokens([40, 17, 33, 1], pad_to=40, seed=12).cuda()
     ref = esmc(tok, drop_pads=True)
-    esmc(tok)  # warm: weight packing, cached batch description
+    one = ESMProteinTensor(sequence=tok[1, :17])
+    cfg = LogitsConfig(sequence=True, return_embeddings=True, return_hidden_states=True, ith_hidden_layer=1)
+    esmc(tok)  # warm: weight packing; the static part of a batch description is uploaded once per (B, L) shape
+    esmc.logits(one, cfg)
     torch.cuda.synchronize()
     torch.cuda.set_sync_debug_mode("error")
     try:
         out = esmc(tok)
-        lo = esmc.logits(ESMProteinTensor(sequence=tok[1, :17]), LogitsConfig(sequence=True, return_embeddings=True,
-                                                                             return_hidden_states=True, ith_hidden_layer=1))
+        lo = esmc.logits(one, cfg)
     finally:
         torch.cuda.set_sync_debug_mode("default")
     torch.cuda.synchronize()
