@@ -43,6 +43,12 @@ constexpr int SLOT = 2 * TILE;        // one ring slot: [K | V]
 #ifndef ESMK_ATTN_MINWG
 #define ESMK_ATTN_MINWG 4
 #endif
+#ifndef ESMK_ATTN_DESC
+#define ESMK_ATTN_DESC 1
+#endif
+#ifndef ESMK_ATTN_WIDE
+#define ESMK_ATTN_WIDE 1
+#endif
 // Measured in one process (tools/attn_ab.py; C2 / C5 / varlen): 2 slots + 4 workgroups per CU (128 VGPRs, 32 KiB) 98.0 /
 // 637 / 287 us; 3 slots + 3 per CU (130 VGPRs, 48 KiB) 103.8 / 655 / 299 us; round-1 kernel 116.7 / 791 / 359 us.
 constexpr int NSLOT = ESMK_ATTN_NSLOT;   // 2: tiles staged one ahead; 3: two ahead with a counted vmcnt, fewer workgroups per CU
@@ -98,6 +104,31 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
     const __bf16* kbase = qkv + (size_t)s0 * ld + d + head * 64;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + d), 0, 0x7fffffff, 0x00020000);
+#if ESMK_ATTN_DESC
+    // Per-lane offsets of piece 0 inside a tile (piece 1 = row + 8: the K swizzle flips chunk bit 2, the V swizzle is
+    // unchanged; ldb is a multiple of 128, so the XOR stays inside the 128-byte row).  The tile's first row goes into
+    // the descriptor base and the rows that exist into its size (scalar arithmetic only): rows past the segment end
+    // are out of range and the DMA writes zeros for them (keys past the end are masked by index below, and a zero V
+    // row times p = 0 is 0 - foreign or NaN rows never enter the V operand).
+    unsigned offK0, offV0;
+    {
+        const int r = wave * 16 + (lane >> 3);
+        offK0 = (unsigned)r * ldb + (unsigned)((lane & 7) ^ ((r >> 1) & 7)) * 16u;
+        offV0 = (unsigned)r * ldb + (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16u;
+    }
+    auto stage = [&](int slot_off, int kt) {
+        char* base = smem + slot_off + wave * 2048;
+        const int rows = min(len - kt * KVBLK, KVBLK);
+        const int nrec = (rows - 1) * (int)ldb + 128;
+        const __bf16* kt0 = kbase + (size_t)kt * KVBLK * ld;
+        const __amdgpu_buffer_rsrc_t tK = __builtin_amdgcn_make_buffer_rsrc((void*)kt0, 0, nrec, 0x00020000);
+        const __amdgpu_buffer_rsrc_t tV = __builtin_amdgcn_make_buffer_rsrc((void*)(kt0 + d), 0, nrec, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tK, LDS_PTR(base), 16, (int)offK0, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tV, LDS_PTR(base + TILE), 16, (int)offV0, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tK, LDS_PTR(base + 1024), 16, (int)((offK0 ^ 64u) + 8u * ldb), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(tV, LDS_PTR(base + TILE + 1024), 16, (int)(offV0 + 8u * ldb), 0, 0, 0);
+    };
+#else
     const int srow = wave * 16 + (lane >> 3);  // this lane's row inside the tile for piece 0 (piece 1: + 8)
     const int pchunk = lane & 7;
     auto stage = [&](int slot_off, int kt) {
@@ -115,6 +146,8 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rV, LDS_PTR(base + TILE + i * 1024), 16, (int)((unsigned)rl * ldb + vc), so, 0, 0);
         }
     };
+
+#endif
 
     // K fragment (A operand) read offsets: row = 32mt + l31, logical chunk = 2ks + hi
     int koff[2];
@@ -344,6 +377,23 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
     }
     if (qr < len) {
         __bf16* op = ctx + (size_t)(s0 + qr) * d + head * 64;
+#if ESMK_ATTN_WIDE
+        // The row is split over the half-waves in 8-byte pieces (lane: dh 8g + 4hi ..+3).  A half exchange per dword
+        // (v_permlane32_swap: the upper half of the first operand swaps with the lower half of the second) on the
+        // piece pairs (g, g+1) leaves 16 contiguous bytes in every lane: dh 8g..8g+7 below, 8g+8..8g+15 above.
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+                const unsigned ax = pack_bf16x2(o[t][4 * g] * inv, o[t][4 * g + 1] * inv);
+                const unsigned ay = pack_bf16x2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
+                const unsigned bx = pack_bf16x2(o[t][4 * g + 4] * inv, o[t][4 * g + 5] * inv);
+                const unsigned by = pack_bf16x2(o[t][4 * g + 6] * inv, o[t][4 * g + 7] * inv);
+                const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                *(u32x4*)(op + 32 * t + 8 * g + 8 * hie) = u32x4{sx[0], sy[0], sx[1], sy[1]};
+            }
+#else
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -353,6 +403,7 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
                 pk.y = pack_bf16x2(o[t][4 * g + 2] * inv, o[t][4 * g + 3] * inv);
                 *(u32x2*)(op + 32 * t + 8 * g + 4 * hie) = pk;
             }
+#endif
     }
 }
 
