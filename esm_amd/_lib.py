@@ -64,6 +64,11 @@ SIGNATURES = {
     "esmk_gemm_noalloc": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp]),
     "esmk_qk_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
     "esmk_qk_prep_ex": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, vp]),
+    "esmk_qkv_stats_parts": (C.c_int, [C.c_int, C.c_int]),
+    "esmk_gemm_qkv_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "esmk_k_prep": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, vp, C.c_int, vp, vp]),
+    "esmk_attn_varlen_qfused": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp,
+                                          vp, vp, vp, C.c_int, C.c_float, vp]),
     "esmk_attn_plan": (C.c_int, [vp, C.c_int, vp, C.c_int]),
     "esmk_attn_varlen": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp]),
     "esmk_attn_l64_d128": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp]),

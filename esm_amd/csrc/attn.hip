@@ -57,11 +57,27 @@ constexpr float L_HI = 1.2676506e30f, L_LO = 7.8886091e-31f;  // 2^100, 2^-100: 
 
 __device__ __forceinline__ int crow(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
 
+// QF instantiation (esmk_attn_varlen_qfused): q arrives RAW from the QKV projection and its QK-LayerNorm (statistics
+// over all d_model columns, attention.py:31-33,51-52), rotary embedding (rotary.py:47-65) and softmax scale are applied
+// to the query fragments in registers, so that q makes no extra trip through HBM.  The row statistics come as partial
+// (sum, sum of squares) pairs from the projection's epilogue (esmk_gemm_qkv_stats).
+struct QFuse {
+    const float* mean_rstd;  // [M][2]: mean and 1/sqrt(var + eps) of the token's q row (esmk_k_prep)
+    const float* gamma;      // q_ln.weight [d]
+    const float* beta;       // q_ln.bias [d] or NULL
+    const int* positions;    // [M]
+    const float* rcos;       // [rope_len][32]
+    const float* rsin;
+    int rope_len;
+    float q_scale;
+};
+
+template <bool QF>
 __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const __bf16* __restrict__ qkv,
                                                             __bf16* __restrict__ ctx,
                                                             const int* __restrict__ cu_seqlens,
                                                             const int* __restrict__ qblk_map, int n_qblk, int d,
-                                                            int H, int nblk, int pad_tail) {
+                                                            int H, int nblk, int pad_tail, QFuse qf_) {
     __shared__ __attribute__((aligned(16))) char smem[NSLOT * SLOT + 16];  // ring + the "redo this block" flag
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,14 +101,12 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
         return;
     }
 
-    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = l31][dh = 16ks + 8hi + j] ----
-    bf16x8 qf[4];
-    {
+    bf16x8 qf[4];  // Q fragments (B operand of S^T = K.Q^T), filled below once the first K/V tile is on its way
+    int qpos = 0;  // QF: the query's rotary position, requested first (its table rows are the only dependent loads)
+    if constexpr (QF) {
         int qr = q0 + wave * 32 + l31;
         qr = qr < len ? qr : len - 1;
-        const __bf16* qp = qkv + (size_t)(s0 + qr) * ld + head * 64 + hi * 8;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+        qpos = qf_.positions[s0 + qr];
     }
 
     // ---- staging: each wave moves 2 K pieces + 2 V pieces (8 rows x 128 B each) per tile.  Per-lane byte offsets
@@ -279,6 +293,62 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
     const bool ragged = (len & (KVBLK - 1)) != 0;  // the last tile holds keys past the end
     stage(0, 0);
     if (LEAD > 1 && nt > 1) stage(SLOT, 1);
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): lane holds Q[q = l31][dh = 16ks + 8hi + j] ----
+    {
+        int qr = q0 + wave * 32 + l31;
+        qr = qr < len ? qr : len - 1;
+        const __bf16* qp = qkv + (size_t)(s0 + qr) * ld + head * 64 + hi * 8;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + ks * 16);
+        if constexpr (QF) {
+            const size_t tok = (size_t)(s0 + qr);
+            const f32x2 mr = *(const f32x2*)(qf_.mean_rstd + tok * 2);
+            const float mean = mr[0], rstd = mr[1] * qf_.q_scale;
+            const int pos = qpos < qf_.rope_len ? qpos : qf_.rope_len - 1;
+            const float* gp = qf_.gamma + head * 64 + hi * 8;
+            const float* bp = qf_.beta ? qf_.beta + head * 64 + hi * 8 : nullptr;  // kernel argument: uniform
+            const float* cp = qf_.rcos + (size_t)pos * 32 + hi * 8;
+            const float* sn = qf_.rsin + (size_t)pos * 32 + hi * 8;
+            // channels of this lane: 16 ks + 8 hi + j; the rotary partner of ks is ks ^ 2 (column +-32), angle 16 (ks&1) + 8 hi + j
+#pragma unroll
+            for (int kl = 0; kl < 2; ++kl) {
+                float a[8], b[8];  // normalised columns below 32 (ks = kl) and their partners (ks = kl + 2)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int ks = kl + 2 * half;
+                    const u32x4 raw = __builtin_bit_cast(u32x4, qf[ks]);
+                    const f32x4 g0 = *(const f32x4*)(gp + ks * 16), g1 = *(const f32x4*)(gp + ks * 16 + 4);
+                    f32x4 b0 = f32x4{0.f, 0.f, 0.f, 0.f}, b1 = b0;
+                    if (bp) {
+                        b0 = *(const f32x4*)(bp + ks * 16) * qf_.q_scale;
+                        b1 = *(const f32x4*)(bp + ks * 16 + 4) * qf_.q_scale;
+                    }
+                    float* dst = half ? b : a;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x0 = __uint_as_float(raw[e] << 16), x1 = __uint_as_float(raw[e] & 0xffff0000u);
+                        const float ga = (e < 2 ? g0[2 * e] : g1[2 * e - 4]) * rstd, gb = (e < 2 ? g0[2 * e + 1] : g1[2 * e - 3]) * rstd;
+                        dst[2 * e] = (x0 - mean) * ga + (e < 2 ? b0[2 * e] : b1[2 * e - 4]);
+                        dst[2 * e + 1] = (x1 - mean) * gb + (e < 2 ? b0[2 * e + 1] : b1[2 * e - 3]);
+                    }
+                }
+                const f32x4 c0 = *(const f32x4*)(cp + kl * 16), c1 = *(const f32x4*)(cp + kl * 16 + 4);
+                const f32x4 s0_ = *(const f32x4*)(sn + kl * 16), s1_ = *(const f32x4*)(sn + kl * 16 + 4);
+                u32x4 lo, hi_;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ca = e < 2 ? c0[2 * e] : c1[2 * e - 4], cb = e < 2 ? c0[2 * e + 1] : c1[2 * e - 3];
+                    const float sa = e < 2 ? s0_[2 * e] : s1_[2 * e - 4], sb = e < 2 ? s0_[2 * e + 1] : s1_[2 * e - 3];
+                    lo[e] = pack_bf16x2(a[2 * e] * ca - b[2 * e] * sa, a[2 * e + 1] * cb - b[2 * e + 1] * sb);
+                    hi_[e] = pack_bf16x2(b[2 * e] * ca + a[2 * e] * sa, b[2 * e + 1] * cb + a[2 * e + 1] * sb);
+                }
+                qf[kl] = __builtin_bit_cast(bf16x8, lo);
+                qf[kl + 2] = __builtin_bit_cast(bf16x8, hi_);
+            }
+        }
+    }
+
     {
         int cur = 0;           // byte offset of the ring slot holding tile kt
         int nxt = LEAD * SLOT; // slot that receives tile kt + LEAD (afterwards: the one read a tile ago)
@@ -445,8 +515,28 @@ int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens,
     if (n_qblk == 0 || M == 0) return ESMK_OK;
     const long long nblk = (long long)n_qblk * H;
     if (nblk > 0x7fffffffLL) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen: grid too large");
-    hipLaunchKernelGGL(attn_varlen_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
-                       (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail);
+    hipLaunchKernelGGL(attn_varlen_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail, QFuse{});
     ESMK_CHECK_LAUNCH("esmk_attn_varlen");
+    return ESMK_OK;
+}
+
+// q raw (as the QKV projection wrote it), k prepared by esmk_k_prep (which also reduced q's statistics); pad_tail as in esmk_batch
+extern "C" int esmk_attn_varlen_qfused(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map,
+                                       int n_qblk, int M, int d, int H, int pad_tail, const float* q_mean_rstd,
+                                       const float* gq, const float* bq, const int32_t* positions, const float* rcos,
+                                       const float* rsin, int rope_len, float q_scale, esmk_stream_t stream) {
+    if (n_qblk == 0 || M == 0) return ESMK_OK;
+    if (!qkv || !ctx || !cu_seqlens || !qblk_map || !q_mean_rstd || !gq || !positions || !rcos || !rsin)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen_qfused: null pointer");
+    if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen_qfused: head dim must be 64 (d=%d, heads=%d)", d, H);
+    if (n_qblk < 0 || M < 0 || rope_len <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen_qfused: bad sizes");
+    if ((uintptr_t)q_mean_rstd & 7) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_attn_varlen_qfused: q_mean_rstd must be 8-byte aligned");
+    const long long nblk = (long long)n_qblk * H;
+    if (nblk > 0x7fffffffLL) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen_qfused: grid too large");
+    QFuse qf{q_mean_rstd, gq, bq, positions, rcos, rsin, rope_len, q_scale};
+    hipLaunchKernelGGL(attn_varlen_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                       (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail ? 1 : 0, qf);
+    ESMK_CHECK_LAUNCH("esmk_attn_varlen_qfused");
     return ESMK_OK;
 }

@@ -262,6 +262,8 @@ int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int
                  float alpha, void* out, hipStream_t s, int n_ctile);
 int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
+int esmk_gemm288_stats(const void* A, int lda, const void* W, int M, int d, int K, void* out, float* stats, int tc,
+                       hipStream_t s);
 
 #ifdef ESMK_EXPERIMENTS
 // Alternative kernels of the experiments build only (libesmk_x.so): the four-wave 128x128-wave-tile kernels
@@ -356,6 +358,39 @@ extern "C" int esmk_gemm_noalloc(const void* A, int lda, const void* W, int M, i
     }
     // every partial the reduce pass reads is written by the first pass of the same call: nothing needs clearing
     return esmk_gemm_ws(A, lda, W, M, N, K, epilogue, bias, alpha, out, part, need, stream);
+}
+
+// Channel-tile width the dispatch below picks for the QKV projection (N = 3 d, K = d, bf16, no bias) when that kernel
+// can also emit the q-side LayerNorm partial sums (tiles must not straddle the q / k boundary); 0 otherwise.
+static int qkv_stats_tile(int M, int d) {
+    if (esmk_switch("ESMK_GEMM_TILE", 0) != 0 || !esmk_switch("ESMK_GEMM_288", 1) || esmk_switch("ESMK_GEMM_192", 0)) return 0;
+    const long long N = 3LL * d, nt = (M + 255) / 256;
+    if ((N % 288) == 0 && (N % 256) != 0 && nt * (N / 288) >= 128) return (d % 288) == 0 ? 288 : 0;
+    if ((N % 192) == 0) {
+        const long long c192 = (nt * (N / 192) + 255) / 256 * 192, c256 = (nt * ((N + 255) / 256) + 255) / 256 * 256;
+        if (nt * (N / 192) >= 128 && c192 < c256) return (d % 192) == 0 ? 192 : 0;
+    }
+    return 0;
+}
+
+extern "C" int esmk_qkv_stats_parts(int M, int d_model) {
+    if (M <= 0 || d_model <= 0) return 0;
+    const int tc = qkv_stats_tile(M, d_model);
+    return tc ? 2 * (d_model / tc) : 0;
+}
+
+extern "C" int esmk_gemm_qkv_stats(const void* A, int lda, const void* W, int M, int d_model, void* out, float* qstats,
+                                   esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (!A || !W || !out || !qstats) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm_qkv_stats: null pointer");
+    if (M < 0 || d_model <= 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm_qkv_stats: bad shape M=%d d=%d", M, d_model);
+    if (lda < round_up(d_model, BK) || (lda & 7))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm_qkv_stats: lda=%d must be >= round_up(d,64) and a multiple of 8", lda);
+    const int tc = qkv_stats_tile(M, d_model);
+    if (!tc)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm_qkv_stats: shape M=%d d=%d has no statistics-emitting kernel "
+                  "(esmk_qkv_stats_parts() == 0): use esmk_gemm + esmk_qk_prep", M, d_model);
+    return esmk_gemm288_stats(A, lda, W, M, d_model, d_model, out, qstats, tc, (hipStream_t)stream);
 }
 
 extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,

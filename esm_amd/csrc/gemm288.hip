@@ -41,10 +41,13 @@ template <int NQM> struct Cfg {
         __builtin_amdgcn_sched_barrier(0);   \
     } while (0)
 
-template <int NQM, bool HI>  // HI: waves 0-3 (six P pieces per K-tile), else five
+// STATS (QKV projection with the q-side QK-LayerNorm moved into the attention kernel): tiles whose channels lie below
+// stat_cols (= d_model: the q columns) also write, per token and per wave half, the sum and the sum of squares of
+// their WC fp32 outputs: stats[token][2 * ctile + wm] = (sum, sum of squares).
+template <int NQM, bool HI, bool STATS>  // HI: waves 0-3 (six P pieces per K-tile), else five
 __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int lda, const __bf16* __restrict__ W, int ldw,
                                              int M, int N, int ktiles, float alpha, __bf16* __restrict__ out, int c0,
-                                             int t0, char* smem) {
+                                             int t0, char* smem, float* __restrict__ stats, int stat_cols) {
     using C = Cfg<NQM>;
     constexpr int KBUF = C::KBUF, PITCH = C::PITCH;
     // Q region = UA1 (.. UA2): 12 (NQM - 1) pieces over 8 waves -> 3 per wave (288) / 2 for waves 0-3 and 1 else (192)
@@ -214,6 +217,11 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     //      fragments after barrier Q of the last tile) and store whole 288-byte row pieces, 16 B per lane ----
     const int q4 = (lane >> 4) * 4;
     char* stg = smem + wave * (64 * PITCH);
+    float ssum[2][2], ssq[2][2];  // STATS: per-token partial sums of this lane's channels, by (qn, ni)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ssum[i][j] = ssq[i][j] = 0.f;
 #pragma unroll
     for (int qm = 0; qm < NQM; ++qm)
 #pragma unroll
@@ -224,12 +232,43 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
 #pragma unroll
                 for (int mi = 0; mi < 3; ++mi) {
                     const f32x4 v = scale4(acc[qm][qn][mi][ni], alpha);
+                    if constexpr (STATS) {  // summed while the values pass through anyway (a separate sweep over the
+                                            // accumulators doubles their live range and spills)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            ssum[qn][ni] += v[e];
+                            ssq[qn][ni] += v[e] * v[e];
+                        }
+                    }
                     u32x2 pk;
                     pk.x = pack_bf16x2(v[0], v[1]);
                     pk.y = pack_bf16x2(v[2], v[3]);
                     *(u32x2*)(stg + trow * PITCH + (qm * 48 + mi * 16 + q4) * 2) = pk;
                 }
             }
+    if constexpr (STATS) {
+        if (c0 < stat_cols) {  // workgroup-uniform
+            const int parts = 2 * (stat_cols / C::TC);
+            const int part = 2 * (c0 / C::TC) + wm;
+#pragma unroll
+            for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    // the four 16-lane groups hold four different channel quads of the same 16 tokens
+                    float sm = ssum[qn][ni], sq = ssq[qn][ni];
+                    sm += __shfl_xor(sm, 16);
+                    sq += __shfl_xor(sq, 16);
+                    sm += __shfl_xor(sm, 32);
+                    sq += __shfl_xor(sq, 32);
+                    const int t = t0 + wn * 64 + qn * 32 + ni * 16 + (lane & 15);
+                    if (lane < 16 && t < M) {
+                        float* sp = stats + ((size_t)t * parts + part) * 2;
+                        sp[0] = sm;
+                        sp[1] = sq;
+                    }
+                }
+        }
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // LPR lanes cover one row of WC channels (288 / 192 bytes): RPI rows per wave instruction
     constexpr int LPR = C::LPR, RPI = C::RPI;
@@ -246,11 +285,12 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     }
 }
 
-template <int NQM>
+template <int NQM, bool STATS>
 __global__ __launch_bounds__(512, 2) void gemm288_kernel(const __bf16* __restrict__ A, int lda,
                                                          const __bf16* __restrict__ W, int ldw, int M, int N,
                                                          int ktiles, float alpha, __bf16* __restrict__ out,
-                                                         int n_ctile, int nblk, int gt) {
+                                                         int n_ctile, int nblk, int gt, float* __restrict__ stats,
+                                                         int stat_cols) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // tile order: see gemm256.hip (XCD-contiguous id ranges, panels of gt token tiles x all channel tiles)
     const int id = xcd_remap(blockIdx.x, nblk);
@@ -261,13 +301,14 @@ __global__ __launch_bounds__(512, 2) void gemm288_kernel(const __bf16* __restric
     const int ctile = idp / gtp, ttile = panel * gt + (idp - ctile * gtp);
     const int c0 = ctile * Cfg<NQM>::TC, t0 = ttile * TT;
     if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 4)
-        gemm288_body<NQM, true>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+        gemm288_body<NQM, true, STATS>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem, stats, stat_cols);
     else
-        gemm288_body<NQM, false>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem);
+        gemm288_body<NQM, false, STATS>(A, lda, W, ldw, M, N, ktiles, alpha, out, c0, t0, smem, stats, stat_cols);
 }
 
-template <int NQM>
-static int launch288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
+template <int NQM, bool STATS = false>
+static int launch288(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s,
+                     float* stats = nullptr, int stat_cols = 0) {
     using C = Cfg<NQM>;
     const int Kpad = round_up(K, BK);
     const int n_ctile = N / C::TC;
@@ -276,10 +317,10 @@ static int launch288(const void* A, int lda, const void* W, int M, int N, int K,
     int gt = esmk_switch("ESMK_GEMM_GT", 4);  // panel width of the tile order (4: best or within noise on every shape)
     if (gt < 1) gt = 1;
     static std::atomic<unsigned long long> lds_ready{0};
-    if (!esmk_reserve_lds((const void*)gemm288_kernel<NQM>, C::LDS_BYTES, lds_ready))
+    if (!esmk_reserve_lds((const void*)gemm288_kernel<NQM, STATS>, C::LDS_BYTES, lds_ready))
         ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(C::LDS_BYTES));
-    hipLaunchKernelGGL(gemm288_kernel<NQM>, dim3(nblk), dim3(512), C::LDS_BYTES, s, (const __bf16*)A, lda, (const __bf16*)W,
-                       Kpad, M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt);
+    hipLaunchKernelGGL((gemm288_kernel<NQM, STATS>), dim3(nblk), dim3(512), C::LDS_BYTES, s, (const __bf16*)A, lda,
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, alpha, (__bf16*)out, n_ctile, nblk, gt, stats, stat_cols);
     ESMK_CHECK_LAUNCH("esmk_gemm(288/192)");
     return ESMK_OK;
 }
@@ -293,4 +334,10 @@ int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, flo
 }
 int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s) {
     return launch288<2>(A, lda, W, M, N, K, alpha, out, s);
+}
+// QKV projection (N = 3 d) that also emits the q-side LayerNorm partial sums; tc = 288 or 192 (d % tc == 0).
+int esmk_gemm288_stats(const void* A, int lda, const void* W, int M, int d, int K, void* out, float* stats, int tc,
+                       hipStream_t s) {
+    if (tc == 288) return launch288<3, true>(A, lda, W, M, 3 * d, K, 1.f, out, s, stats, d);
+    return launch288<2, true>(A, lda, W, M, 3 * d, K, 1.f, out, s, stats, d);
 }

@@ -158,17 +158,23 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 }
 
 // LN = false (qk_layernorm=False block variant, attention.py:34-38): rotary and the q scale only.
-template <int NU, bool LN = true>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
+// KONLY: the k half alone (units = chunks of k; the q half is normalised and rotated by the attention kernel's prologue,
+// esmk_attn_varlen_qfused); NU = ceil(8*H / 64) then.
+template <int NU, bool LN = true, bool KONLY = false>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
 __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
                                                       const float* __restrict__ gk, const float* __restrict__ bq,
                                                       const float* __restrict__ bk,
                                                       const int* __restrict__ positions,
                                                       const float* __restrict__ rcos,
                                                       const float* __restrict__ rsin, int rope_len, int M, int d,
-                                                      int H, float q_scale, float eps) {
+                                                      int H, float q_scale, float eps,
+                                                      const float* __restrict__ qstats, int parts,
+                                                      float* __restrict__ q_mean_rstd) {
     const int lane = threadIdx.x & 63;
     const int units_half = 8 * H;  // chunks of q; same count for k
-    const int nunits = 2 * units_half;
+    const int units_q = KONLY ? 0 : units_half;
+    const int nunits = units_q + units_half;
+    const int col0 = KONLY ? d : 0;  // first column of the region inside the token's [q | k | v] row
     const int stride = gridDim.x * 4;
     int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     // Only the LAST unit of a lane can fall outside the row (NU = ceil(nunits/64)): its lanes read chunk 0 again
@@ -182,22 +188,25 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
         const int unit = lane + u * 64;
         const bool on = (u < NU - 1) || last_on;
         uoff[u] = on ? unit * 8 : 0;
-        kw[u] = (on && unit >= units_half) ? 1.0f : 0.0f;
+        kw[u] = (on && unit >= units_q) ? 1.0f : 0.0f;
     }
     u32x4 raw[NU];
     int pos_next = 0;
+    f32x2 part_next = f32x2{0.f, 0.f};  // KONLY with qstats: lane p < parts holds partial p of the token's q statistics
     auto load_tok = [&](int t) {
-        const __bf16* row = qkv + (size_t)t * 3 * d;
+        const __bf16* row = qkv + (size_t)t * 3 * d + col0;
 #pragma unroll
         for (int u = 0; u < NU; ++u) raw[u] = *(const u32x4*)(row + uoff[u]);
         pos_next = positions[t];
+        if constexpr (KONLY)
+            if (qstats && lane < parts) part_next = *(const f32x2*)(qstats + ((size_t)t * parts + lane) * 2);
     };
     if (tok < M) load_tok(tok);
     const float inv_d = 1.0f / (float)d;
     const int j0 = (lane & 3) * 8;                 // rotary frequency index of this lane's element 0
     const float sgn = (lane & 4) ? 1.0f : -1.0f;   // first half: x1*c - x2*s; second half: x2*c + x1*s
     for (; tok < M; tok += stride) {
-        __bf16* row = qkv + (size_t)tok * 3 * d;
+        __bf16* row = qkv + (size_t)tok * 3 * d + col0;
         float v[NU][8];
         float st = 0.f, sk = 0.f;  // sum over q and k together, and over k alone
 #pragma unroll
@@ -211,7 +220,19 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
             sk += s * kw[u];
         }
         int pos = pos_next;
+        const f32x2 part = part_next;
         if (tok + stride < M) load_tok(tok + stride);
+        if constexpr (KONLY) {
+            if (qstats) {  // kernel argument: uniform.  Partials -> (mean, rstd) of the token's q row for the attention
+                           // prologue; they combine like parallel variances (each partial's cancellation stays its own)
+                const float n_i = (float)d / (float)parts;
+                const float on = lane < parts ? 1.0f : 0.0f;
+                const float mean_q = wave_sum(part[0] * on) * inv_d;
+                const float mi = part[0] / n_i;
+                const float m2 = wave_sum(on * ((part[1] - part[0] * mi) + n_i * (mi - mean_q) * (mi - mean_q)));
+                if (lane == 0) *(f32x2*)(q_mean_rstd + (size_t)tok * 2) = f32x2{mean_q, rsqrtf(fmaxf(m2 * inv_d, 0.f) + eps)};
+            }
+        }
         float rstd_k = 1.0f, rstd_q = q_scale;
         if constexpr (LN) {
             st = wave_sum(st);
@@ -249,11 +270,11 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
             f32x4 ga = f32x4{rs, rs, rs, rs}, gb = ga;
             f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bb = ba;  // biased q_ln / k_ln (bias=True blocks): beta, q's scaled like q
             if constexpr (LN) {
-                const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
+                const float* g = (isk ? gk - units_q * 8 : gq) + uoff[u];
                 ga = *(const f32x4*)g * rs;
                 gb = *(const f32x4*)(g + 4) * rs;
                 if (bq) {  // kernel argument: uniform
-                    const float* b = (isk ? bk - units_half * 8 : bq) + uoff[u];
+                    const float* b = (isk ? bk - units_q * 8 : bq) + uoff[u];
                     const float bs = isk ? 1.0f : q_scale;
                     ba = *(const f32x4*)b * bs;
                     bb = *(const f32x4*)(b + 4) * bs;
@@ -459,10 +480,10 @@ extern "C" int esmk_qk_prep_ex(void* qkv, const float* gq, const float* gk, cons
         if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
         if (ln)                                                                                                \
             hipLaunchKernelGGL((qk_prep_kernel<NU, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, \
-                               gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);            \
+                               gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps, nullptr, 0, nullptr); \
         else                                                                                                   \
             hipLaunchKernelGGL((qk_prep_kernel<NU, false>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, \
-                               gq, gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps);        \
+                               gq, gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps, nullptr, 0, nullptr); \
     } while (0)
     switch (nu) {
         case 1: QK_LAUNCH(1); break;
@@ -477,6 +498,41 @@ extern "C" int esmk_qk_prep_ex(void* qkv, const float* gq, const float* gk, cons
     }
 #undef QK_LAUNCH
     ESMK_CHECK_LAUNCH("esmk_qk_prep");
+    return ESMK_OK;
+}
+
+// The k half alone: q is normalised and rotated inside the attention kernel (esmk_attn_varlen_qfused).
+extern "C" int esmk_k_prep(void* qkv, const float* gk, const float* bk, const int32_t* positions, const float* rcos,
+                           const float* rsin, int rope_len, int M, int d, int H, float eps, const float* qstats, int parts,
+                           float* q_mean_rstd, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (!qkv || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: null pointer");
+    if (qstats && (!q_mean_rstd || parts < 1 || parts > 64 || (d % parts) || ((uintptr_t)qstats & 7) || ((uintptr_t)q_mean_rstd & 7)))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: qstats needs q_mean_rstd (both 8-byte aligned) and 1 <= parts <= 64 dividing d");
+    if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_k_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
+    const int nu = (8 * H + 63) / 64;
+    if (nu > QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_k_prep: too many heads (%d)", H);
+    if (rope_len <= 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: bad sizes");
+    const dim3 block(256);
+    hipStream_t s = (hipStream_t)stream;
+    // the q-side arguments of the kernel are unused in this instantiation; beta_q only says "biased" (uniform branch)
+#define K_LAUNCH(NU)                                                                                           \
+    do {                                                                                                       \
+        static int cap = 0;                                                                                    \
+        if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU, true, true>, 0, 1 << 30, 8);                  \
+        hipLaunchKernelGGL((qk_prep_kernel<NU, true, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gk, \
+                           gk, bk, bk, positions, rcos, rsin, rope_len, M, d, H, 1.0f, eps, qstats, parts, q_mean_rstd); \
+    } while (0)
+    switch (nu) {
+        case 1: K_LAUNCH(1); break;
+        case 2: K_LAUNCH(2); break;
+        case 3: K_LAUNCH(3); break;
+        case 4: K_LAUNCH(4); break;
+        case 5: K_LAUNCH(5); break;
+        default: K_LAUNCH(6); break;
+    }
+#undef K_LAUNCH
+    ESMK_CHECK_LAUNCH("esmk_k_prep");
     return ESMK_OK;
 }
 

@@ -36,7 +36,8 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TrunkWs {
-    size_t xn, qkv, ctx, hbuf, dbuf, dbuf2, gproj, gout, gscratch, splitk, splitk_bytes, total;
+    size_t xn, qkv, ctx, hbuf, dbuf, dbuf2, gproj, gout, gscratch, splitk, splitk_bytes, qstats, qmr, total;
+    int qparts;  // > 0: the q side of QK-LayerNorm + rotary runs inside the attention kernel (esmk_attn_varlen_qfused)
 };
 
 TrunkWs trunk_layout(const esmk_trunk* t, int M) {
@@ -63,6 +64,9 @@ TrunkWs trunk_layout(const esmk_trunk* t, int M) {
     need(3 * (int)d, (int)d); need((int)d, (int)d); need(2 * (int)h, (int)d); need((int)d, (int)h);
     if (geom) { need(15 * t->v_heads, (int)d); need((int)d, 3 * t->v_heads); }
     w.splitk = off; w.splitk_bytes = sk; off += align256(sk);
+    w.qparts = esmk_qkv_stats_parts(M, (int)d);
+    w.qstats = off; off += align256((size_t)M * w.qparts * 2 * sizeof(float));
+    w.qmr = off; off += align256(w.qparts ? (size_t)M * 2 * sizeof(float) : 0);
     w.total = off;
     return w;
 }
@@ -153,9 +157,20 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
             if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
                 ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
         }
-        TRY(esmk_gemm_ws(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, skp, w.splitk_bytes, stream));
-        TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
-        TRY(esmk_attn_varlen_impl(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, b->pad_tail ? 1 : 0, stream));
+        if (w.qparts > 0) {
+            // q_ln + rotary of q inside the attention kernel, statistics from the projection's epilogue; k in a k-only pass
+            float* qstats = (float*)(ws + w.qstats);
+            float* qmr = (float*)(ws + w.qmr);
+            TRY(esmk_gemm_qkv_stats(xn, d, L.w_qkv, M, d, qkv, qstats, stream));
+            TRY(esmk_k_prep(qkv, L.kln_g, nullptr, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, eps, qstats,
+                            w.qparts, qmr, stream));
+            TRY(esmk_attn_varlen_qfused(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, b->pad_tail ? 1 : 0, qmr,
+                                        L.qln_g, nullptr, b->positions, t->rope_cos, t->rope_sin, t->rope_len, q_scale, stream));
+        } else {
+            TRY(esmk_gemm_ws(xn, d, L.w_qkv, M, 3 * d, d, ESMK_EPI_BF16, nullptr, 1.f, qkv, skp, w.splitk_bytes, stream));
+            TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
+            TRY(esmk_attn_varlen_impl(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, b->pad_tail ? 1 : 0, stream));
+        }
         TRY(esmk_gemm_ws(ctx, d, L.w_o, M, d, d, ESMK_EPI_BF16, nullptr, inv_s, dbufA, skp, w.splitk_bytes, stream));
         pa = dbufA;
         // --- x += GeomAttn(x) / s  (geom_attention.py:52-149, blocks.py:150-152)

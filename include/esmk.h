@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define ESMK_VERSION 200
+#define ESMK_VERSION 210
 
 #define ESMK_OK 0
 #define ESMK_ERR_INVALID_ARG (-1)
@@ -172,6 +172,33 @@ int esmk_qk_prep_ex(void* qkv_bf16, const float* gamma_q, const float* gamma_k, 
 int esmk_attn_plan(const int32_t* cu_seqlens_host, int n_segments, int32_t* qblk_map_host, int capacity);
 int esmk_attn_varlen(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seqlens, const int32_t* qblk_map,
                      int n_qblk, int M, int d, int n_heads, esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * The q side of QK-LayerNorm + rotary fused into the attention kernel (q makes no extra trip through HBM).
+ * Replaces, together: q_ln / k_ln (reference attention.py:31-33,51-52), RotaryEmbedding (rotary.py:47-65, attention.py:
+ * 53-54) and the attention itself (attention.py:65-78,117-119) - the same results as esmk_gemm + esmk_qk_prep_ex +
+ * esmk_attn_varlen up to bf16 rounding, as three calls:
+ *   1. esmk_gemm_qkv_stats: qkv = A . W_qkv^T (bf16 [M, 3d], what esmk_gemm(EPI_BF16) writes) and, from the fp32
+ *      accumulators of the q columns, qstats f32 [M][parts][2] = (sum, sum of squares) over d/parts columns each.
+ *      parts = esmk_qkv_stats_parts(M, d): 0 when the GEMM kernel that this shape dispatches to has tiles straddling
+ *      the q / k boundary or emits no statistics (then use the three separate calls).
+ *   2. esmk_k_prep: k_ln (gamma_k, beta_k or NULL) + rotary on the k columns only, in place; and, when qstats is given,
+ *      the partials reduced to q_mean_rstd f32 [M][2] = (mean, 1/sqrt(var + eps)) of every token's q row (qstats NULL:
+ *      k only).  qstats / q_mean_rstd 8-byte aligned.
+ *   3. esmk_attn_varlen_qfused: normalises (gamma_q, beta_q or NULL, q_mean_rstd), rotates (positions, rope tables as
+ *      in esmk_qk_prep) and scales its query fragments in registers, then runs esmk_attn_varlen's loop.
+ *      pad_tail as in esmk_batch.
+ * ------------------------------------------------------------------------------------------ */
+int esmk_qkv_stats_parts(int M, int d_model);
+int esmk_gemm_qkv_stats(const void* A_bf16, int lda, const void* W_qkv_packed, int M, int d_model, void* qkv_bf16,
+                        float* qstats, esmk_stream_t stream);
+int esmk_k_prep(void* qkv_bf16, const float* gamma_k, const float* beta_k, const int32_t* positions,
+                const float* rope_cos, const float* rope_sin, int rope_len, int M, int d, int n_heads, float eps,
+                const float* qstats, int parts, float* q_mean_rstd, esmk_stream_t stream);
+int esmk_attn_varlen_qfused(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seqlens, const int32_t* qblk_map,
+                            int n_qblk, int M, int d, int n_heads, int pad_tail, const float* q_mean_rstd,
+                            const float* gamma_q, const float* beta_q, const int32_t* positions, const float* rope_cos,
+                            const float* rope_sin, int rope_len, float q_scale, esmk_stream_t stream);
 
 /* Attention of the function-token decoder's stack (reference esm/models/function_decoder.py:92-103,172-174:
  * TransformerStack(d 1024, 8 heads => head dim 128, qk_layernorm=False) on sequences of exactly 64 tokens with
