@@ -158,23 +158,17 @@ __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 }
 
 // LN = false (qk_layernorm=False block variant, attention.py:34-38): rotary and the q scale only.
-// KONLY: the k half alone (units = chunks of k; the q half is normalised and rotated by the attention kernel's prologue,
-// esmk_attn_varlen_qfused); NU = ceil(8*H / 64) then.
-template <int NU, bool LN = true, bool KONLY = false>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
+template <int NU, bool LN = true>  // units per lane (compile-time so the row stays in registers); NU = ceil(16*H / 64)
 __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gq,
                                                       const float* __restrict__ gk, const float* __restrict__ bq,
                                                       const float* __restrict__ bk,
                                                       const int* __restrict__ positions,
                                                       const float* __restrict__ rcos,
                                                       const float* __restrict__ rsin, int rope_len, int M, int d,
-                                                      int H, float q_scale, float eps,
-                                                      const float* __restrict__ qstats, int parts,
-                                                      float* __restrict__ q_mean_rstd) {
+                                                      int H, float q_scale, float eps) {
     const int lane = threadIdx.x & 63;
     const int units_half = 8 * H;  // chunks of q; same count for k
-    const int units_q = KONLY ? 0 : units_half;
-    const int nunits = units_q + units_half;
-    const int col0 = KONLY ? d : 0;  // first column of the region inside the token's [q | k | v] row
+    const int nunits = 2 * units_half;
     const int stride = gridDim.x * 4;
     int tok = blockIdx.x * 4 + (threadIdx.x >> 6);
     // Only the LAST unit of a lane can fall outside the row (NU = ceil(nunits/64)): its lanes read chunk 0 again
@@ -188,25 +182,22 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
         const int unit = lane + u * 64;
         const bool on = (u < NU - 1) || last_on;
         uoff[u] = on ? unit * 8 : 0;
-        kw[u] = (on && unit >= units_q) ? 1.0f : 0.0f;
+        kw[u] = (on && unit >= units_half) ? 1.0f : 0.0f;
     }
     u32x4 raw[NU];
     int pos_next = 0;
-    f32x2 part_next = f32x2{0.f, 0.f};  // KONLY with qstats: lane p < parts holds partial p of the token's q statistics
     auto load_tok = [&](int t) {
-        const __bf16* row = qkv + (size_t)t * 3 * d + col0;
+        const __bf16* row = qkv + (size_t)t * 3 * d;
 #pragma unroll
         for (int u = 0; u < NU; ++u) raw[u] = *(const u32x4*)(row + uoff[u]);
         pos_next = positions[t];
-        if constexpr (KONLY)
-            if (qstats && lane < parts) part_next = *(const f32x2*)(qstats + ((size_t)t * parts + lane) * 2);
     };
     if (tok < M) load_tok(tok);
     const float inv_d = 1.0f / (float)d;
     const int j0 = (lane & 3) * 8;                 // rotary frequency index of this lane's element 0
     const float sgn = (lane & 4) ? 1.0f : -1.0f;   // first half: x1*c - x2*s; second half: x2*c + x1*s
     for (; tok < M; tok += stride) {
-        __bf16* row = qkv + (size_t)tok * 3 * d + col0;
+        __bf16* row = qkv + (size_t)tok * 3 * d;
         float v[NU][8];
         float st = 0.f, sk = 0.f;  // sum over q and k together, and over k alone
 #pragma unroll
@@ -220,19 +211,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
             sk += s * kw[u];
         }
         int pos = pos_next;
-        const f32x2 part = part_next;
         if (tok + stride < M) load_tok(tok + stride);
-        if constexpr (KONLY) {
-            if (qstats) {  // kernel argument: uniform.  Partials -> (mean, rstd) of the token's q row for the attention
-                           // prologue; they combine like parallel variances (each partial's cancellation stays its own)
-                const float n_i = (float)d / (float)parts;
-                const float on = lane < parts ? 1.0f : 0.0f;
-                const float mean_q = wave_sum(part[0] * on) * inv_d;
-                const float mi = part[0] / n_i;
-                const float m2 = wave_sum(on * ((part[1] - part[0] * mi) + n_i * (mi - mean_q) * (mi - mean_q)));
-                if (lane == 0) *(f32x2*)(q_mean_rstd + (size_t)tok * 2) = f32x2{mean_q, rsqrtf(fmaxf(m2 * inv_d, 0.f) + eps)};
-            }
-        }
         float rstd_k = 1.0f, rstd_q = q_scale;
         if constexpr (LN) {
             st = wave_sum(st);
@@ -270,11 +249,11 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
             f32x4 ga = f32x4{rs, rs, rs, rs}, gb = ga;
             f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bb = ba;  // biased q_ln / k_ln (bias=True blocks): beta, q's scaled like q
             if constexpr (LN) {
-                const float* g = (isk ? gk - units_q * 8 : gq) + uoff[u];
+                const float* g = (isk ? gk - units_half * 8 : gq) + uoff[u];
                 ga = *(const f32x4*)g * rs;
                 gb = *(const f32x4*)(g + 4) * rs;
                 if (bq) {  // kernel argument: uniform
-                    const float* b = (isk ? bk - units_q * 8 : bq) + uoff[u];
+                    const float* b = (isk ? bk - units_half * 8 : bq) + uoff[u];
                     const float bs = isk ? 1.0f : q_scale;
                     ba = *(const f32x4*)b * bs;
                     bb = *(const f32x4*)(b + 4) * bs;
@@ -288,6 +267,124 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
                 o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
             }
             if (u < NU - 1 || last_on)
+                *(u32x4*)(row + uoff[u]) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
+                                                 pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------------
+// The k half alone (esmk_k_prep; q is normalised and rotated by the attention kernel's prologue): k_ln over the d_model
+// columns of k + rotary, in place.  A k row is half the bytes of the [q | k] row above, so one HALF-wave owns a token
+// (two tokens per wave instruction stream: the per-token latency chain - loads, two reductions, table rows - is
+// amortised as before); reductions are five xor steps inside the half.  Lane l of the half owns chunks l, l + 32, ...
+// of its token's k row; the rotary partner is still lane ^ 4.  With qstats, lanes p < parts of the half also reduce the
+// token's q partials (esmk_gemm_qkv_stats) to (mean, rstd) like parallel variances (each partial's cancellation stays
+// its own).  Measured at 32768 x 1152 (tools/kprep_ab.py, k from HBM): 42 us = 151 MB at 3.6 TB/s; without the store 30,
+// without the table rows 37, without the q statistics 39; flat from 2 to 8 resident blocks per CU, and a whole wave per
+// token measured the same - the pass touches one third of every [q | k | v] row, and reads 2304-byte pieces 6912 bytes
+// apart slower than the [q | k] pass reads its 4608 (5.0 TB/s) or the LayerNorm passes their contiguous rows (6.3).
+// --------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float half_sum(float v) {
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+template <int NU>  // chunks per lane: ceil(8*H / 32)
+__global__ __launch_bounds__(256) void k_prep_kernel(__bf16* __restrict__ qkv, const float* __restrict__ gk,
+                                                     const float* __restrict__ bk, const int* __restrict__ positions,
+                                                     const float* __restrict__ rcos, const float* __restrict__ rsin,
+                                                     int rope_len, int M, int d, int H, float eps,
+                                                     const float* __restrict__ qstats, int parts,
+                                                     float* __restrict__ q_mean_rstd) {
+    const int lane = threadIdx.x & 63, l32 = lane & 31;
+    const int nunits = 8 * H;
+    const int stride = gridDim.x * 8;
+    int tok = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool last_on = l32 + (NU - 1) * 32 < nunits;  // only the last chunk of a lane can fall outside the row
+    const float last_w = last_on ? 1.0f : 0.0f;
+    int uoff[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) uoff[u] = ((u < NU - 1) || last_on) ? (l32 + u * 32) * 8 : 0;
+    u32x4 raw[NU];
+    int pos_next = 0;
+    f32x2 part_next = f32x2{0.f, 0.f};
+    // a half past the end re-reads the last token and stores nothing (it still takes part in every exchange)
+    auto load_tok = [&](int t) {
+        const int tc = t < M ? t : M - 1;
+        const __bf16* row = qkv + (size_t)tc * 3 * d + d;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) raw[u] = *(const u32x4*)(row + uoff[u]);
+        pos_next = positions[tc];
+        if (qstats && l32 < parts) part_next = *(const f32x2*)(qstats + ((size_t)tc * parts + l32) * 2);
+    };
+    const int tok_w = tok - (lane >> 5);  // first token of the wave: the loop condition is wave-uniform
+    if (tok_w < M) load_tok(tok);
+    const float inv_d = 1.0f / (float)d;
+    const int j0 = (lane & 3) * 8;
+    const float sgn = (lane & 4) ? 1.0f : -1.0f;
+    for (int tw = tok_w; tw < M; tw += stride, tok += stride) {
+        const bool live = tok < M;
+        __bf16* row = qkv + (size_t)(live ? tok : M - 1) * 3 * d + d;
+        float v[NU][8];
+        float st = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            unpack8(raw[u], v[u]);
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += v[u][e];
+            if (u == NU - 1) s *= last_w;
+            st += s;
+        }
+        int pos = pos_next;
+        const f32x2 part = part_next;
+        if (tw + stride < M) load_tok(tok + stride);
+        if (qstats) {  // kernel argument: uniform
+            const float n_i = (float)d / (float)parts;
+            const float on = l32 < parts ? 1.0f : 0.0f;
+            const float mean_q = half_sum(part[0] * on) * inv_d;
+            const float mi = part[0] / n_i;
+            const float m2 = half_sum(on * ((part[1] - part[0] * mi) + n_i * (mi - mean_q) * (mi - mean_q)));
+            if (l32 == 0 && live) *(f32x2*)(q_mean_rstd + (size_t)tok * 2) = f32x2{mean_q, rsqrtf(fmaxf(m2 * inv_d, 0.f) + eps)};
+        }
+        const float mean = half_sum(st) * inv_d;
+        st = 0.f;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[u][e] -= mean;
+                s += v[u][e] * v[u][e];
+            }
+            if (u == NU - 1) s *= last_w;
+            st += s;
+        }
+        const float rstd = rsqrtf(half_sum(st) * inv_d + eps);
+        pos = pos < rope_len ? pos : rope_len - 1;  // host validates; clamp keeps the load in bounds
+        const float* cs = rcos + (size_t)pos * 32 + j0;
+        const float* sn = rsin + (size_t)pos * 32 + j0;
+        const f32x4 c0 = *(const f32x4*)cs, c1 = *(const f32x4*)(cs + 4);
+        const f32x4 s0 = *(const f32x4*)sn * sgn, s1 = *(const f32x4*)(sn + 4) * sgn;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const float* g = gk + uoff[u];
+            const f32x4 ga = *(const f32x4*)g * rstd, gb = *(const f32x4*)(g + 4) * rstd;
+            f32x4 ba = f32x4{0.f, 0.f, 0.f, 0.f}, bb = ba;
+            if (bk) {  // kernel argument: uniform
+                ba = *(const f32x4*)(bk + uoff[u]);
+                bb = *(const f32x4*)(bk + uoff[u] + 4);
+            }
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]) + (e < 4 ? ba[e & 3] : bb[e & 3]);
+                const float pn = __shfl_xor(n, 4);
+                o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
+            }
+            if (live && (u < NU - 1 || last_on))
                 *(u32x4*)(row + uoff[u]) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]),
                                                  pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
         }
@@ -480,10 +577,10 @@ extern "C" int esmk_qk_prep_ex(void* qkv, const float* gq, const float* gk, cons
         if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
         if (ln)                                                                                                \
             hipLaunchKernelGGL((qk_prep_kernel<NU, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, \
-                               gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps, nullptr, 0, nullptr); \
+                               gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps); \
         else                                                                                                   \
             hipLaunchKernelGGL((qk_prep_kernel<NU, false>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, \
-                               gq, gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps, nullptr, 0, nullptr); \
+                               gq, gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps); \
     } while (0)
     switch (nu) {
         case 1: QK_LAUNCH(1); break;
@@ -507,21 +604,20 @@ extern "C" int esmk_k_prep(void* qkv, const float* gk, const float* bk, const in
                            float* q_mean_rstd, esmk_stream_t stream) {
     if (M == 0) return ESMK_OK;
     if (!qkv || !gk || !positions || !rcos || !rsin) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: null pointer");
-    if (qstats && (!q_mean_rstd || parts < 1 || parts > 64 || (d % parts) || ((uintptr_t)qstats & 7) || ((uintptr_t)q_mean_rstd & 7)))
-        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: qstats needs q_mean_rstd (both 8-byte aligned) and 1 <= parts <= 64 dividing d");
+    if (qstats && (!q_mean_rstd || parts < 1 || parts > 32 || (d % parts) || ((uintptr_t)qstats & 7) || ((uintptr_t)q_mean_rstd & 7)))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: qstats needs q_mean_rstd (both 8-byte aligned) and 1 <= parts <= 32 dividing d");
     if (d != H * 64) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_k_prep: head dim must be 64 (d=%d, heads=%d)", d, H);
-    const int nu = (8 * H + 63) / 64;
-    if (nu > QK_MAX_UNITS) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_k_prep: too many heads (%d)", H);
+    const int nu = (8 * H + 31) / 32;
+    if (nu > 12) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_k_prep: too many heads (%d)", H);
     if (rope_len <= 0 || M < 0) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_k_prep: bad sizes");
     const dim3 block(256);
     hipStream_t s = (hipStream_t)stream;
-    // the q-side arguments of the kernel are unused in this instantiation; beta_q only says "biased" (uniform branch)
 #define K_LAUNCH(NU)                                                                                           \
     do {                                                                                                       \
         static int cap = 0;                                                                                    \
-        if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU, true, true>, 0, 1 << 30, 8);                  \
-        hipLaunchKernelGGL((qk_prep_kernel<NU, true, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gk, \
-                           gk, bk, bk, positions, rcos, rsin, rope_len, M, d, H, 1.0f, eps, qstats, parts, q_mean_rstd); \
+        if (cap == 0) cap = persistent_blocks(k_prep_kernel<NU>, 0, 1 << 30, 8);  /* flat from 2 to 8 per CU */   \
+        hipLaunchKernelGGL((k_prep_kernel<NU>), dim3(min((M + 7) / 8, cap)), block, 0, s, (__bf16*)qkv, gk, bk,  \
+                           positions, rcos, rsin, rope_len, M, d, H, eps, qstats, parts, q_mean_rstd);          \
     } while (0)
     switch (nu) {
         case 1: K_LAUNCH(1); break;
@@ -529,7 +625,10 @@ extern "C" int esmk_k_prep(void* qkv, const float* gk, const float* bk, const in
         case 3: K_LAUNCH(3); break;
         case 4: K_LAUNCH(4); break;
         case 5: K_LAUNCH(5); break;
-        default: K_LAUNCH(6); break;
+        case 6: K_LAUNCH(6); break;
+        case 7: case 8: K_LAUNCH(8); break;
+        case 9: case 10: K_LAUNCH(10); break;
+        default: K_LAUNCH(12); break;
     }
 #undef K_LAUNCH
     ESMK_CHECK_LAUNCH("esmk_k_prep");

@@ -15,8 +15,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def short(name):
     for key, lab in (("gemm256_kernel<2>", "gemm256<SWIGLU> (FFN up-projection)"), ("gemm256_kernel", "gemm256 (other epilogues)"),
-                     ("gemm288", "gemm288 (QKV / out-proj / FFN down-projection)"), ("attn_varlen", "attn_varlen"),
-                     ("qk_prep", "qk_prep"), ("layernorm_kernel", "add+layernorm"), ("gemm_kernel", "gemm 128-tile"),
+                     ("gemm288_kernel<3, true>", "gemm288 + q statistics (QKV projection)"),
+                     ("gemm288_kernel<2, true>", "gemm288 + q statistics (QKV projection)"),
+                     ("gemm288", "gemm288 (out-proj / FFN down-projection; QKV where not fused)"),
+                     ("attn_varlen_kernel<true>", "attn_varlen, q-fused"), ("attn_varlen", "attn_varlen"),
+                     ("qk_prep_kernel<3, true, true>", "k_prep (k-only QK-LayerNorm + rotary)"), ("qk_prep", "qk_prep"), ("layernorm_kernel", "add+layernorm"), ("gemm_kernel", "gemm 128-tile"),
                      ("splitk_reduce", "split-K reduce")):
         if key in name:
             return lab
