@@ -1,6 +1,8 @@
 // Row-wise, HBM-bound kernels: LayerNorm, QK-LayerNorm + rotary, embedding gathers.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace {
@@ -149,6 +151,15 @@ void launch_layernorm(const void* x, const float* gamma, const float* beta, void
 // --------------------------------------------------------------------------------------------------
 constexpr int QK_MAX_UNITS = 12;  // per lane -> 16*H <= 768 -> H <= 48
 
+// value of lane ^ 4 by two bank-masked DPP moves (rows of 16 lanes = 4 banks of 4: banks 0 / 2 take lane + 4, banks
+// 1 / 3 lane - 4) - vector ALU only, where __shfl_xor goes through the LDS crossbar (ds_bpermute + wait)
+__device__ __forceinline__ float lane_xor4(float v) {
+    const int x = __float_as_int(v);
+    int r = __builtin_amdgcn_update_dpp(0, x, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    r = __builtin_amdgcn_update_dpp(r, x, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+    return __int_as_float(r);
+}
+
 __device__ __forceinline__ void unpack8(const u32x4 p, float* f) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]) + (e < 4 ? ba[e & 3] : bb[e & 3]);
-                const float pn = __shfl_xor(n, 4);
+                const float pn = lane_xor4(n);
                 o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
             }
             if (u < NU - 1 || last_on)
@@ -285,10 +296,15 @@ __global__ __launch_bounds__(256) void qk_prep_kernel(__bf16* __restrict__ qkv, 
 // token measured the same - the pass touches one third of every [q | k | v] row, and reads 2304-byte pieces 6912 bytes
 // apart slower than the [q | k] pass reads its 4608 (5.0 TB/s) or the LayerNorm passes their contiguous rows (6.3).
 // --------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float half_sum(float v) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+__device__ __forceinline__ float half_sum(float v) {  // sum over the lane's 32-lane half, in every lane of it
+    auto dpp = [](float x, auto ctrl) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xb1>{});   // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp(v, std::integral_constant<int, 0x4e>{});   // quad_perm [2,3,0,1]: lane ^ 2
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror: the other quad of the 8
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror: the other 8 of the row
+    return v + __shfl_xor(v, 16);
 }
 
 template <int NU>  // chunks per lane: ceil(8*H / 32)
@@ -315,7 +331,7 @@ __global__ __launch_bounds__(256) void k_prep_kernel(__bf16* __restrict__ qkv, c
         const int tc = t < M ? t : M - 1;
         const __bf16* row = qkv + (size_t)tc * 3 * d + d;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) raw[u] = *(const u32x4*)(row + uoff[u]);
+        for (int u = 0; u < NU; ++u) raw[u] = __builtin_nontemporal_load((const u32x4*)(row + uoff[u]));
         pos_next = positions[tc];
         if (qstats && l32 < parts) part_next = *(const f32x2*)(qstats + ((size_t)tc * parts + l32) * 2);
     };
@@ -381,7 +397,7 @@ __global__ __launch_bounds__(256) void k_prep_kernel(__bf16* __restrict__ qkv, c
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float n = v[u][e] * (e < 4 ? ga[e & 3] : gb[e & 3]) + (e < 4 ? ba[e & 3] : bb[e & 3]);
-                const float pn = __shfl_xor(n, 4);
+                const float pn = lane_xor4(n);
                 o[e] = n * (e < 4 ? c0[e & 3] : c1[e & 3]) + pn * (e < 4 ? s0[e & 3] : s1[e & 3]);
             }
             if (live && (u < NU - 1 || last_on))
