@@ -31,6 +31,8 @@
 namespace {
 
 constexpr int QBLK = ESMK_ATTN_QBLK;  // 128 query rows per workgroup
+constexpr int WAVES = QBLK / 32;       // one wave per 32 query rows
+constexpr int RPW = 64 / WAVES;    // K (and V) tile rows each wave stages
 constexpr int KVBLK = 64;
 constexpr int TILE = KVBLK * 128;     // bytes per K (or V) tile
 constexpr int SLOT = 2 * TILE;        // one ring slot: [K | V]
@@ -73,7 +75,7 @@ struct QFuse {
 };
 
 template <bool QF>
-__global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const __bf16* __restrict__ qkv,
+__global__ __launch_bounds__(WAVES * 64, ESMK_ATTN_MINWG) void attn_varlen_kernel(const __bf16* __restrict__ qkv,
                                                             __bf16* __restrict__ ctx,
                                                             const int* __restrict__ cu_seqlens,
                                                             const int* __restrict__ qblk_map, int n_qblk, int d,
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, 0x7fffffff, 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)(kbase + d), 0, 0x7fffffff, 0x00020000);
 #if ESMK_ATTN_DESC
+    static_assert(RPW == 16 || RPW == 8, "4 or 8 waves per workgroup");
     // Per-lane offsets of piece 0 inside a tile (piece 1 = row + 8: the K swizzle flips chunk bit 2, the V swizzle is
     // unchanged; ldb is a multiple of 128, so the XOR stays inside the 128-byte row).  The tile's first row goes into
     // the descriptor base and the rows that exist into its size (scalar arithmetic only): rows past the segment end
@@ -126,12 +129,12 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
     // row times p = 0 is 0 - foreign or NaN rows never enter the V operand).
     unsigned offK0, offV0;
     {
-        const int r = wave * 16 + (lane >> 3);
+        const int r = wave * RPW + (lane >> 3);
         offK0 = (unsigned)r * ldb + (unsigned)((lane & 7) ^ ((r >> 1) & 7)) * 16u;
         offV0 = (unsigned)r * ldb + (unsigned)((lane & 7) ^ (((r >> 1) & 1) << 2)) * 16u;
     }
     auto stage = [&](int slot_off, int kt) {
-        char* base = smem + slot_off + wave * 2048;
+        char* base = smem + slot_off + wave * (RPW * 128);
         const int rows = min(len - kt * KVBLK, KVBLK);
         const int nrec = (rows - 1) * (int)ldb + 128;
         const __bf16* kt0 = kbase + (size_t)kt * KVBLK * ld;
@@ -139,8 +142,10 @@ __global__ __launch_bounds__(256, ESMK_ATTN_MINWG) void attn_varlen_kernel(const
         const __amdgpu_buffer_rsrc_t tV = __builtin_amdgcn_make_buffer_rsrc((void*)(kt0 + d), 0, nrec, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(tK, LDS_PTR(base), 16, (int)offK0, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(tV, LDS_PTR(base + TILE), 16, (int)offV0, 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(tK, LDS_PTR(base + 1024), 16, (int)((offK0 ^ 64u) + 8u * ldb), 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(tV, LDS_PTR(base + TILE + 1024), 16, (int)(offV0 + 8u * ldb), 0, 0, 0);
+        if constexpr (RPW == 16) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tK, LDS_PTR(base + 1024), 16, (int)((offK0 ^ 64u) + 8u * ldb), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(tV, LDS_PTR(base + TILE + 1024), 16, (int)(offV0 + 8u * ldb), 0, 0, 0);
+        }
     };
 #else
     const int srow = wave * 16 + (lane >> 3);  // this lane's row inside the tile for piece 0 (piece 1: + 8)
@@ -515,7 +520,7 @@ int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens,
     if (n_qblk == 0 || M == 0) return ESMK_OK;
     const long long nblk = (long long)n_qblk * H;
     if (nblk > 0x7fffffffLL) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen: grid too large");
-    hipLaunchKernelGGL(attn_varlen_kernel<false>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_varlen_kernel<false>, dim3((unsigned)nblk), dim3(WAVES * 64), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail, QFuse{});
     ESMK_CHECK_LAUNCH("esmk_attn_varlen");
     return ESMK_OK;
@@ -535,7 +540,7 @@ extern "C" int esmk_attn_varlen_qfused(const void* qkv, void* ctx, const int32_t
     const long long nblk = (long long)n_qblk * H;
     if (nblk > 0x7fffffffLL) ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_attn_varlen_qfused: grid too large");
     QFuse qf{q_mean_rstd, gq, bq, positions, rcos, rsin, rope_len, q_scale};
-    hipLaunchKernelGGL(attn_varlen_kernel<true>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(attn_varlen_kernel<true>, dim3((unsigned)nblk), dim3(WAVES * 64), 0, (hipStream_t)stream,
                        (const __bf16*)qkv, (__bf16*)ctx, cu_seqlens, qblk_map, n_qblk, d, H, (int)nblk, pad_tail ? 1 : 0, qf);
     ESMK_CHECK_LAUNCH("esmk_attn_varlen_qfused");
     return ESMK_OK;

@@ -168,7 +168,9 @@ int esmk_qk_prep_ex(void* qkv_bf16, const float* gamma_q, const float* gamma_k, 
  * esmk_attn_plan is HOST-side: it fills qblk_map_host with (segment, first query row in segment)
  * pairs, 128 query rows per block, and returns the number of blocks (or <0).  Pass NULL to count.
  * ------------------------------------------------------------------------------------------ */
+#ifndef ESMK_ATTN_QBLK
 #define ESMK_ATTN_QBLK 128
+#endif
 int esmk_attn_plan(const int32_t* cu_seqlens_host, int n_segments, int32_t* qblk_map_host, int capacity);
 int esmk_attn_varlen(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seqlens, const int32_t* qblk_map,
                      int n_qblk, int M, int d, int n_heads, esmk_stream_t stream);

@@ -17,9 +17,18 @@ for name, lens, H in (("c2 64x512 H18", [512] * 64, 18), ("c5 4x4096 H40", [4096
     N = pb.n_tokens
     qkv = (torch.randn(N, 3 * d, device="cuda") * 0.6).bfloat16()   # |q.k| * log2e/8-scale scores like the model's
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).cuda()
-    cu, qmap = dev(pb.cu_seqlens), dev(pb.qblk_map.reshape(-1))
+    cu = dev(pb.cu_seqlens)
+    cu_h = np.ascontiguousarray(pb.cu_seqlens, dtype=np.int32)
+    maps = {}
+    for n, lib in libs:   # every library plans with its own query-block size
+        nq = lib.esmk_attn_plan(cu_h.ctypes.data, len(cu_h) - 1, None, 0)
+        m = np.zeros((nq, 2), dtype=np.int32)
+        lib.esmk_attn_plan(cu_h.ctypes.data, len(cu_h) - 1, m.ctypes.data, nq)
+        maps[n] = (dev(m.reshape(-1)), nq)
     outs = [torch.empty(N, d, device="cuda", dtype=torch.bfloat16) for _ in libs]
-    run = lambda lib, o: L.check(lib.esmk_attn_varlen(qkv.data_ptr(), o.data_ptr(), cu.data_ptr(), qmap.data_ptr(), pb.qblk_map.shape[0], N, d, H, st))
+    names = {id(lib): n for n, lib in libs}
+    run = lambda lib, o: L.check(lib.esmk_attn_varlen(qkv.data_ptr(), o.data_ptr(), cu.data_ptr(), maps[names[id(lib)]][0].data_ptr(),
+                                                      maps[names[id(lib)]][1], N, d, H, st))
     for (n, lib), o in zip(libs, outs):
         for _ in range(3):
             run(lib, o)
