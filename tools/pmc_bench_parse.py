@@ -18,8 +18,9 @@ def short(name):
                      ("gemm288_kernel<3, true>", "gemm288 + q statistics (QKV projection)"),
                      ("gemm288_kernel<2, true>", "gemm288 + q statistics (QKV projection)"),
                      ("gemm288", "gemm288 (out-proj / FFN down-projection; QKV where not fused)"),
-                     ("attn_varlen_kernel<true>", "attn_varlen, q-fused"), ("attn_varlen", "attn_varlen"),
-                     ("qk_prep_kernel<3, true, true>", "k_prep (k-only QK-LayerNorm + rotary)"), ("qk_prep", "qk_prep"), ("layernorm_kernel", "add+layernorm"), ("gemm_kernel", "gemm 128-tile"),
+                     ("attn_varlen_kernel<true>", "attn_varlen, q-fused"), ("attn_varlen_kernelILb1E", "attn_varlen, q-fused"),
+                     ("attn_varlen", "attn_varlen"), ("qk_prep", "qk_prep"),
+                     ("k_prep_kernel", "k_prep (k-only QK-LayerNorm + rotary, q statistics)"), ("layernorm_kernel", "add+layernorm"), ("gemm_kernel", "gemm 128-tile"),
                      ("splitk_reduce", "split-K reduce")):
         if key in name:
             return lab
