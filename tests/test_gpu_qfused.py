@@ -118,6 +118,31 @@ def test_qfused_against_reference_and_three_call_path(lens, H, biased):
     assert (b - ref).pow(2).mean().sqrt().item() <= 1.1 * (a - ref).pow(2).mean().sqrt().item() + 1e-4
 
 
+@pytest.mark.parametrize("M,H", [(1, 2), (7, 15), (300, 18), (129, 40)])
+def test_k_prep_alone_matches_qk_prep_on_k(M, H):
+    """esmk_k_prep without q statistics (qstats NULL) on any head count / token count, odd tails included: the k
+    columns equal esmk_qk_prep's, q and v are untouched."""
+    from esm_amd import _lib as L
+    from esm_amd import engine
+    lib = L.lib()
+    d = 64 * H
+    g = torch.Generator().manual_seed(M * 31 + H)
+    qkv = (torch.randn(M, 3 * d, generator=g) * 1.5 + 0.3).bfloat16().cuda()
+    gq, gk = (1 + 0.1 * torch.randn(d, generator=g)).cuda(), (1 + 0.1 * torch.randn(d, generator=g)).cuda()
+    pos = torch.randint(0, 700, (M,), generator=g).int().cuda()
+    cos, sin = [t.cuda() for t in engine.rotary_tables(700)]
+    a, b = qkv.clone(), qkv.clone()
+    L.check(lib.esmk_qk_prep(a.data_ptr(), gq.data_ptr(), gk.data_ptr(), pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), 700, M, d, H,
+                             0.18, 1e-5, _s()))
+    L.check(lib.esmk_k_prep(b.data_ptr(), gk.data_ptr(), None, pos.data_ptr(), cos.data_ptr(), sin.data_ptr(), 700, M, d, H, 1e-5,
+                            None, 0, None, _s()))
+    torch.cuda.synchronize()
+    assert torch.equal(b[:, :d], qkv[:, :d]) and torch.equal(b[:, 2 * d:], qkv[:, 2 * d:])
+    ka, kb = a[:, d:2 * d].float(), b[:, d:2 * d].float()
+    assert torch.isfinite(kb).all()
+    assert (ka - kb).abs().max().item() <= 0.01 * ka.abs().max().item()
+
+
 def test_qfused_rejects_bad_arguments():
     from esm_amd import _lib as L
     lib = L.lib()
