@@ -8,7 +8,7 @@ from esm_amd import engine
 
 
 def main():
-    lib = L.lib()
+    lib = L.lib_experiments()  # the ESMK_GEMM_* switches exist in libesmk_x.so only
     st = torch.cuda.current_stream().cuda_stream
     for M, N, K in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (256, 256, 256), (512, 512, 192), (200, 256, 192)]:
         g = torch.Generator().manual_seed(1)

@@ -7,7 +7,7 @@ from esm_amd import _lib as L
 from esm_amd import engine
 
 def main():
-    lib = L.lib(); st = torch.cuda.current_stream().cuda_stream
+    lib = L.lib_experiments(); st = torch.cuda.current_stream().cuda_stream
     for M, N, K in ((8192, 1536, 1536), (8192, 1536, 4096), (8192, 4608, 1536), (16384, 1536, 1536), (16384, 4608, 1536)):
         A = torch.randn(M, K, device="cuda").bfloat16()
         Wp = engine.pack_weight(torch.randn(N, K) * 0.05, "cuda")

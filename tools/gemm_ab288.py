@@ -7,7 +7,7 @@ from esm_amd import _lib as L
 from esm_amd import engine
 
 def main():
-    lib = L.lib(); st = torch.cuda.current_stream().cuda_stream
+    lib = L.lib_experiments(); st = torch.cuda.current_stream().cuda_stream
     for M, N, K in ((32768, 2304, 1152), (32768, 2304, 3072), (32768, 2304, 9216), (32768, 4608, 1152)):
         A = torch.randn(M, K, device="cuda").bfloat16()
         Wp = engine.pack_weight(torch.randn(N, K) * 0.05, "cuda")
