@@ -461,6 +461,27 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
             }
         }
     }
+    // small problems with a short K (<= 20 K-steps: d_model <= 1280 as K) and at least 128 tiles of 128 x 64: those tiles
+    // (twice the workgroups, no partials, no reduce launch) instead of split-K.  Measured with operands coming from HBM,
+    // as inside a forward (tools/small_gemm_ab.py): 2048 x 960 x 960 24.5 -> 18.2 us, 1024 x 2880 x 960 28.2 -> 20.6,
+    // 2048 x 1152 x 1152 26.0 -> 21.7; with fewer tiles (512 x 1536 x 1536: 21.9 vs 25.5) or a longer K (512 x 1536 x
+    // 4096: 22.4 vs 38.3) too few workgroups pull the weights and split-K below stays ahead.  C1 (8 x 256, d 960) forward:
+    // 3.79 -> 3.67 ms in one process.
+    {
+        const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+        const long long tiles64 = (long long)((M + 63) / 64) * ((N + 127) / 128);
+        const int ksteps = round_up(K, BK) / BK;
+        if (esmk_switch("ESMK_GEMM_TILE", 0) == 0 && esmk_switch("ESMK_GEMM_BT64", 1) && tiles128 < 192 && tiles64 >= 128 &&
+            ksteps <= 20) {
+            switch (epilogue) {
+                case ESMK_EPI_BF16: return launch_gemm<ESMK_EPI_BF16, 64>(A, lda, W, M, N, K, bias, alpha, out, s);
+                case ESMK_EPI_F32: return launch_gemm<ESMK_EPI_F32, 64>(A, lda, W, M, N, K, bias, alpha, out, s);
+                case ESMK_EPI_RESIDUAL: return launch_gemm<ESMK_EPI_RESIDUAL, 64>(A, lda, W, M, N, K, bias, alpha, out, s);
+                case ESMK_EPI_BIAS_GELU: return launch_gemm<ESMK_EPI_BIAS_GELU, 64>(A, lda, W, M, N, K, bias, alpha, out, s);
+                default: break;  // SwiGLU: measured slower on 64-token tiles (512 x 8192 x 1536: 25.4 -> 31.5 us)
+            }
+        }
+    }
     // small problems: split K over several workgroups per tile when the caller lent a workspace for the partials
     // (not for the read-modify-write residual epilogue: its output is also an input)
     const int splitk_on = esmk_switch("ESMK_GEMM_SPLITK", 1);

@@ -180,7 +180,8 @@ def test_trunk_fused_and_unfused_paths_agree_on_a_padded_batch():
     for name in ("embeddings", "sequence_logits"):
         a, b = getattr(fused, name).cpu()[valid], getattr(plain, name).cpu()[valid]
         assert torch.isfinite(a).all()
-        assert (a - b).abs().max().item() <= 0.01 * max(1.0, b.abs().max().item()), name
+        # two valid kernel paths (other GEMM tilings, other statistics source) through two bf16 blocks and the head
+        assert (a - b).abs().max().item() <= 0.02 * max(1.0, b.abs().max().item()), name
         cosv = torch.nn.functional.cosine_similarity(a, b, dim=-1).min().item()
         assert cosv >= 0.9995, (name, cosv)
     assert fused.embeddings.cpu()[~valid].abs().max().item() == 0.0
