@@ -134,3 +134,76 @@ def test_c5_80_layers_4x4096_properties():
     # and it must NOT equal another row
     c_other = torch.nn.functional.cosine_similarity(post_1, post_a[:L], dim=-1).mean().item()
     assert c_other < 0.9, c_other
+
+
+def _c4_model():
+    from esm_amd.esmc import ESMC
+    d, H, NL = 1152, 18, 36
+    w = synth.esmc_weights(d, NL, seed=0)
+    m = ESMC(d, H, NL)
+    m.load_state_dict(w)
+    return m.cuda(), w, (d, H, NL)
+
+
+@pytest.mark.timeout(600)
+def test_c4_full_size_packs_vs_oracle():
+    """BASELINE.json config 4 at its size: the bench's own 4096 lengths (log-uniform 64..2048, seed 7) cut into the real
+    <= 32768-token packs by dp.make_packs; the pack holding the longest sequence and the pack holding the shortest run
+    through the 36-layer d 1152 model, and the longest, a median and the shortest sequence of each pack are checked
+    against the oracle run on that sequence ALONE (reference: attention.py:65-72 equality mask == one segment per
+    sequence, esmc.py:142-164 un-pad / re-pad, utils/misc.py:209-262 bin packing).  A 2048-long segment next to short
+    ones in one pack mixes 16-query-block segments with ragged single-block ones in one attention launch."""
+    import bench
+    from esm_amd.dp import esmc_compute_fn, make_packs
+    from oracle import trunk_ref  # checker only
+    m, w, (d, H, NL) = _c4_model()
+    lengths = bench.c4_lengths()
+    assert len(lengths) == 4096 and min(lengths) >= 64 and max(lengths) <= 2048
+    packs = make_packs(lengths, bench.C4_BUDGET)
+    assert all(sum(lengths[i] for i in p) <= 32768 for p in packs) and sorted(i for p in packs for i in p) == list(range(4096))
+    fn = esmc_compute_fn(m)
+    i_long, i_short = max(range(4096), key=lambda i: lengths[i]), min(range(4096), key=lambda i: lengths[i])
+    chosen = [next(p for p in packs if i_long in p), next(p for p in packs if i_short in p)]
+    assert chosen[0] is not chosen[1]
+    for p in chosen:
+        toks = [synth.synth_tokens([lengths[i]], seed=9000 + i)[0] for i in p]
+        n_tok = sum(lengths[i] for i in p)
+        assert n_tok > 16000  # real packs (the last pack of the plan is the 17 k-token remainder)
+        post = fn(torch.cat(toks).cuda(), [lengths[i] for i in p])
+        torch.cuda.synchronize()
+        assert post.shape == (n_tok, d) and torch.isfinite(post).all()
+        offs = [0]
+        for i in p:
+            offs.append(offs[-1] + lengths[i])
+        by_len = sorted(range(len(p)), key=lambda j: lengths[p[j]])
+        picks = {by_len[-1], by_len[len(by_len) // 2], by_len[0]}   # longest, median, shortest of this pack
+        # the logits of the same positions come from a forward of the pack with the head on
+        from esm_amd.engine import DeviceBatch
+        from esm_amd.packing import pack_lengths
+        logits, post2, _ = m.forward_packed(torch.cat(toks).cuda(), DeviceBatch(pack_lengths([lengths[i] for i in p]), "cuda"))
+        assert torch.equal(post2, post)  # deterministic, head or no head
+        for j in picks:
+            ref = trunk_ref.esmc_forward(toks[j][None], w, H, NL)
+            got = post[offs[j]:offs[j + 1]].float().cpu()
+            emb_ok(got[None], ref["embeddings"], f"pack seq len {lengths[p[j]]}")
+            logits_ok(logits[offs[j]:offs[j + 1]].cpu()[None], ref["sequence_logits"], f"logits len {lengths[p[j]]}")
+
+
+@pytest.mark.timeout(600)
+def test_c4_dp_runner_equals_direct_forward():
+    """run_data_parallel(gather="none") over 256 of the C4 sequences (every 16th of the bench's list, so the whole
+    length range) in 32768-token packs == each sequence's own forward."""
+    import bench
+    from esm_amd.dp import esmc_compute_fn, run_data_parallel
+    m, _w, (d, _H, _NL) = _c4_model()
+    lengths = bench.c4_lengths()[::16]
+    assert len(lengths) == 256
+    seqs = [synth.synth_tokens([n], seed=500 + i)[0] for i, n in enumerate(lengths)]
+    res = run_data_parallel(seqs, esmc_compute_fn(m), d, d=d, h=3072, token_budget=bench.C4_BUDGET,
+                            device=torch.device("cuda"), wire_dtype=torch.float32, gather="none")
+    worst = 1.0
+    for s, r in zip(seqs, res):
+        direct = m(s[None].cuda(), return_hidden_states=False).embeddings[0]
+        worst = min(worst, torch.nn.functional.cosine_similarity(r, direct, dim=-1).min().item())
+        assert (r - direct).abs().max().item() <= 0.1
+    assert worst >= 0.9995, worst
