@@ -84,6 +84,8 @@ SIGNATURES = {
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
     "esmk_trunk_forward_ex": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, C.c_int, vp, C.c_size_t, vp]),
     "esmk_segments_from_tokens": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
+    "esmk_compact_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "esmk_unpack_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),
     "esmk_sample_track": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_float, C.c_float, vp, vp, vp, vp, vp, vp, vp, vp]),
     "esmk_dim6_frames": (C.c_int, [vp, C.c_int, C.c_float, vp, vp, C.c_int, vp]),

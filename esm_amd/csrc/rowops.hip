@@ -45,7 +45,9 @@ template <typename TIN, typename TOUT, int ADD, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, TOUT* __restrict__ y, int M,
                                                         int d, int ldy, float eps, const __bf16* __restrict__ delta,
-                                                        const __bf16* __restrict__ delta2) {
+                                                        const __bf16* __restrict__ delta2, float* xw) {
+    // xw: where the updated row goes (ADD 1 / 3).  The trunk passes another buffer than x when this pass also
+    // captures a hidden state: the residual stream then simply lives on in that buffer (no copy).
     extern __shared__ __attribute__((aligned(16))) float gb[];  // gamma[d] | beta[d]
     using RAW = typename LnRaw<TIN>::type;
     const int lane = threadIdx.x & 63;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
                 if constexpr (ADD != 0) v[i] += ln_cvt(dr[i]);
                 if constexpr (ADD == 3) v[i] += ln_cvt(dr2[i]);
                 if constexpr (ADD == 1 || ADD == 3)
-                    __builtin_nontemporal_store(v[i], (f32x4*)((float*)x + (size_t)row * d + c * 4));
+                    __builtin_nontemporal_store(v[i], (f32x4*)(xw + (size_t)row * d + c * 4));
                 sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
             }
         }
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TIN* x, const floa
 
 template <typename TIN, typename TOUT, int ADD>
 void launch_layernorm(const void* x, const float* gamma, const float* beta, void* y, int M, int d, float eps,
-                      const void* delta, hipStream_t s, const void* delta2 = nullptr) {
+                      const void* delta, hipStream_t s, const void* delta2 = nullptr, float* xw = nullptr) {
+    if (!xw) xw = (float*)x;  // in place
     const int nv = (d / 4 + 63) / 64;
     const size_t lds = (size_t)2 * d * sizeof(float);
 #define LN_LAUNCH(NV)                                                                                                \
@@ -129,7 +132,7 @@ void launch_layernorm(const void* x, const float* gamma, const float* beta, void
         if (cap == 0) cap = persistent_blocks(layernorm_kernel<TIN, TOUT, ADD, NV>, lds, 1 << 30, 4);                \
         hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, ADD, NV>), dim3(min((M + 3) / 4, cap)), dim3(256), lds, s,   \
                            (const TIN*)x, gamma, beta, (TOUT*)y, M, d, d, eps, (const __bf16*)delta,                 \
-                           (const __bf16*)delta2);                                                                   \
+                           (const __bf16*)delta2, xw);                                                               \
     } while (0)
     if (nv <= 2) LN_LAUNCH(2);
     else if (nv <= 4) LN_LAUNCH(4);
@@ -540,6 +543,22 @@ extern "C" int esmk_add_layernorm(float* x, const void* delta, const float* gamm
     return ESMK_OK;
 }
 
+// Internal form used by the trunk: x_out = x_in + delta_a + delta_b (both deltas required), y = LN(x_out).  x_out may be
+// another buffer than x_in (hidden-state capture without a copy).
+int esmk_add2_layernorm_io(const float* x_in, float* x_out, const void* delta_a, const void* delta_b, const float* gamma,
+                           const float* beta, void* y, int y_dtype, int M, int d, float eps, esmk_stream_t stream) {
+    if (M == 0) return ESMK_OK;
+    if (!x_in || !x_out || !delta_a || !delta_b || !gamma || !y) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add2_layernorm: null pointer");
+    if (M < 0 || d <= 0 || (d & 3) || d > LN_MAX_VEC * 256)
+        ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_add2_layernorm: d=%d must be a multiple of 4 and <= %d", d, LN_MAX_VEC * 256);
+    hipStream_t s = (hipStream_t)stream;
+    if (y_dtype == ESMK_BF16) launch_layernorm<float, __bf16, 3>(x_in, gamma, beta, y, M, d, eps, delta_a, s, delta_b, x_out);
+    else if (y_dtype == ESMK_F32) launch_layernorm<float, float, 3>(x_in, gamma, beta, y, M, d, eps, delta_a, s, delta_b, x_out);
+    else ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_add2_layernorm: bad dtype");
+    ESMK_CHECK_LAUNCH("esmk_add2_layernorm");
+    return ESMK_OK;
+}
+
 extern "C" int esmk_add2_layernorm(float* x, const void* delta_a, const void* delta_b, int write_x, const float* gamma,
                                    const float* beta, void* y, int y_dtype, int M, int d, float eps,
                                    esmk_stream_t stream) {
@@ -658,23 +677,21 @@ __global__ __launch_bounds__(256) void segments_from_tokens_kernel(const int64_t
                                                                    int* __restrict__ err) {
     __shared__ int s_len, s_bad;
     const int b = blockIdx.x;
-    if (threadIdx.x == 0) { s_len = 0; s_bad = 0; }
+    if (threadIdx.x == 0) { s_len = L; s_bad = 0; }
     __syncthreads();
-    int len = 0, bad = 0;
+    int first_pad = L, bad = 0;  // valid prefix = the leading run of real tokens (what the header documents)
     const int64_t* row = tokens + (size_t)b * L;
     for (int i = threadIdx.x; i < L; i += blockDim.x) {
         const long long t = row[i];
         const bool v = mask ? mask[(size_t)b * L + i] != 0 : t != pad_id;
-        if (v) {
-            ++len;
-            if (i > 0) {  // a real token behind a padding position: the row is not right-padded
-                const bool pv = mask ? mask[(size_t)b * L + i - 1] != 0 : row[i - 1] != pad_id;
-                if (!pv) ++bad;
-            }
+        if (!v) first_pad = min(first_pad, i);
+        if (v && i > 0) {  // a real token behind a padding position: the row is not right-padded
+            const bool pv = mask ? mask[(size_t)b * L + i - 1] != 0 : row[i - 1] != pad_id;
+            if (!pv) ++bad;
         }
         if (t < 0 || t >= vocab) ++bad;
     }
-    if (len) atomicAdd(&s_len, len);
+    if (first_pad < L) atomicMin(&s_len, first_pad);
     if (bad) atomicAdd(&s_bad, bad);
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -694,6 +711,113 @@ extern "C" int esmk_segments_from_tokens(const int64_t* tokens, const uint8_t* m
     hipLaunchKernelGGL(segments_from_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, mask, L,
                        (long long)pad_id, vocab, B, cu_seqlens, err_count);
     ESMK_CHECK_LAUNCH("esmk_segments_from_tokens");
+    return ESMK_OK;
+}
+
+// Device-side batch description of a [B, L] token matrix with ANY padding pattern (reference semantics of
+// `sequence_id = tokens != pad`, esmc.py:133-135 with attention.py:65-72: the non-pad tokens of a row attend to each
+// other wherever they sit, rotary position = column).  One block per row: the non-pad tokens are moved to the front of
+// the row's L slots in their original order (a no-op for right-padded rows), the pad tokens behind them.
+//   cu[2b], cu[2b+1], cu[2B]   segment bounds: valid tokens of row b, then its padding slots
+//   perm[b*L + j]              flat source index (b*L + column) of the token now in slot j
+//   positions[b*L + j]         its column = rotary position
+//   tok_out[b*L + j]           the token itself
+__global__ __launch_bounds__(256) void compact_tokens_kernel(const int64_t* __restrict__ tokens, int L, long long pad_id,
+                                                             int vocab, int B, int* __restrict__ cu, int* __restrict__ perm,
+                                                             int* __restrict__ positions, int64_t* __restrict__ tok_out,
+                                                             int* __restrict__ err) {
+    __shared__ int s_wave[4], s_total, s_bad;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t* row = tokens + (size_t)b * L;
+    if (tid == 0) { s_total = 0; s_bad = 0; }
+    __syncthreads();
+    int cnt = 0, bad = 0;
+    for (int i = tid; i < L; i += 256) {
+        const long long t = row[i];
+        cnt += t != pad_id;
+        bad += (t < 0 || t >= vocab);
+    }
+    cnt = (int)wave_sum((float)cnt);  // exact: counts stay far below 2^24
+    if (lane == 0 && cnt) atomicAdd(&s_total, cnt);
+    if (bad) atomicAdd(&s_bad, bad);
+    __syncthreads();
+    const int n_valid = s_total;
+    int base_v = 0, base_p = 0;  // valid / pad tokens in the chunks already placed
+    for (int i0 = 0; i0 < L; i0 += 256) {
+        const int i = i0 + tid;
+        const long long t = i < L ? row[i] : pad_id;
+        const bool in = i < L, v = in && t != pad_id;
+        const unsigned long long m = __ballot(v);
+        const int rank_in_wave = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, chunk_v = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            before += w < wave ? s_wave[w] : 0;
+            chunk_v += s_wave[w];
+        }
+        if (in) {
+            const int vr = base_v + before + rank_in_wave;              // rank among the row's valid tokens
+            const int j = v ? vr : n_valid + (i - vr);                  // pads: their rank among the pads
+            const size_t o = (size_t)b * L + j;
+            perm[o] = b * L + i;
+            positions[o] = i;
+            tok_out[o] = t;
+        }
+        base_v += chunk_v;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        cu[2 * b] = b * L;
+        cu[2 * b + 1] = b * L + n_valid;
+        if (b == B - 1) cu[2 * B] = B * L;
+        if (s_bad && err) atomicAdd(err, s_bad);
+    }
+}
+
+// Inverse of the compaction, in place, on n_mat matrices [B*L, w] f32: row slot j of batch row b goes back to its source
+// column, padding columns become zero (the reference's pad_input, esmc.py:159-164).  A thread owns one float4 column
+// and walks the valid slots from the last to the first: a token only ever moves right (source column >= slot), so the
+// slot it lands on has already been read.  Right-padded rows move nothing.
+__global__ __launch_bounds__(256) void unpack_rows_kernel(float* __restrict__ x, const int* __restrict__ perm,
+                                                          const int* __restrict__ cu, int L, int w, size_t mat_stride) {
+    const int b = blockIdx.x;
+    const int c = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (c >= w) return;
+    float* base = x + (size_t)blockIdx.z * mat_stride;
+    const int r0 = b * L, n_valid = cu[2 * b + 1] - r0;
+    for (int j = n_valid - 1; j >= 0; --j) {
+        const int src = perm[r0 + j];
+        if (src != r0 + j) *(f32x4*)(base + (size_t)src * w + c) = *(const f32x4*)(base + (size_t)(r0 + j) * w + c);
+    }
+    for (int j = n_valid; j < L; ++j) *(f32x4*)(base + (size_t)perm[r0 + j] * w + c) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+extern "C" int esmk_compact_tokens(const int64_t* tokens, int B, int L, int64_t pad_id, int vocab, int32_t* cu_seqlens,
+                                   int32_t* perm, int32_t* positions, int64_t* tokens_out, int32_t* err_count,
+                                   esmk_stream_t stream) {
+    if (B == 0) return ESMK_OK;
+    if (!tokens || !cu_seqlens || !perm || !positions || !tokens_out)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_compact_tokens: null pointer");
+    if (B < 0 || L <= 0 || vocab <= 0 || (long long)B * L > 0x7fffffffLL)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_compact_tokens: bad sizes B=%d L=%d", B, L);
+    if (tokens == tokens_out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_compact_tokens: tokens_out must not alias tokens");
+    hipLaunchKernelGGL(compact_tokens_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, tokens, L, (long long)pad_id, vocab,
+                       B, cu_seqlens, perm, positions, tokens_out, err_count);
+    ESMK_CHECK_LAUNCH("esmk_compact_tokens");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_unpack_rows(float* x, int n_mat, int B, int L, int w, const int32_t* perm, const int32_t* cu_seqlens,
+                                esmk_stream_t stream) {
+    if (B == 0 || n_mat == 0) return ESMK_OK;
+    if (!x || !perm || !cu_seqlens) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_unpack_rows: null pointer");
+    if (B < 0 || n_mat < 0 || n_mat > 65535 || L <= 0 || w <= 0 || (w & 3) || ((uintptr_t)x & 15))
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_unpack_rows: bad sizes (w must be a multiple of 4, x 16-byte aligned)");
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3(B, (w / 4 + 255) / 256, n_mat), dim3(256), 0, (hipStream_t)stream, x, perm,
+                       cu_seqlens, L, w, (size_t)B * L * w);
+    ESMK_CHECK_LAUNCH("esmk_unpack_rows");
     return ESMK_OK;
 }
 

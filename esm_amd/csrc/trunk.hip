@@ -11,6 +11,8 @@
 static thread_local char g_err[512] = "";
 
 int esmk_cast_f32_bf16(const float* in, void* out, size_t n, hipStream_t s);
+int esmk_add2_layernorm_io(const float* x_in, float* x_out, const void* delta_a, const void* delta_b, const float* gamma,
+                           const float* beta, void* y, int y_dtype, int M, int d, float eps, esmk_stream_t stream);
 int esmk_attn_varlen_impl(const void* qkv, void* ctx, const int32_t* cu_seqlens, const int32_t* qblk_map, int n_qblk,
                           int M, int d, int H, int pad_tail, esmk_stream_t stream);
 
@@ -138,12 +140,22 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
     void* skp = w.splitk_bytes ? (void*)(ws + w.splitk) : nullptr;
     const void* pa = nullptr;    // pending deltas, oldest first
     const void* pb = nullptr;
-    // x = x + pending deltas (written back), y = LN(x)
-    auto flush_ln = [&](const float* g, const float* be, void* y, int ydt) -> int {
+    // Hidden states without copies: the pass that folds both pending deltas at the head of block i writes the updated
+    // stream (= block i-1's output) straight into its hiddens slot when that block is captured, and the stream lives
+    // on in that slot (xc) until the next folding pass moves it again - back into the caller's x, or into the next slot.
+    float* xc = x;
+    auto slot = [&](int layer) -> float* {
+        if (!hiddens || !(hidden_layer < 0 || hidden_layer == layer)) return nullptr;
+        return hidden_layer < 0 ? hiddens + (size_t)layer * M * d : hiddens;
+    };
+    // xo = xc + pending deltas (written), y = LN(xo); the stream moves to xo
+    auto flush_ln = [&](const float* g, const float* be, void* y, int ydt, float* xo) -> int {
         int rc;
-        if (pa && pb) rc = esmk_add2_layernorm(x, pa, pb, 1, g, be, y, ydt, M, d, eps, stream);
-        else rc = esmk_add_layernorm(x, pa, g, be, y, ydt, M, d, eps, stream);  // pa may be NULL: plain LayerNorm
+        if (pa && pb) rc = esmk_add2_layernorm_io(xc, xo, pa, pb, g, be, y, ydt, M, d, eps, stream);
+        else if (xo != xc) ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: internal: stream move without two pending deltas");
+        else rc = esmk_add_layernorm(xc, pa, g, be, y, ydt, M, d, eps, stream);  // pa may be NULL: plain LayerNorm
         pa = pb = nullptr;
+        xc = xo;
         return rc;
     };
     for (int i = 0; i < t->n_layers; ++i) {
@@ -151,11 +163,9 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
         if (!L.ln1_g || !L.ln1_b || !L.w_qkv || !L.qln_g || !L.kln_g || !L.w_o || !L.ln2_g || !L.ln2_b || !L.w_ffn1 || !L.w_ffn2)
             ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
         // --- x += MHA(x) / s  (attention.py:48-82, blocks.py:146-148)
-        TRY(flush_ln(L.ln1_g, L.ln1_b, xn, ESMK_BF16));
-        if (hiddens && i > 0 && (hidden_layer < 0 || hidden_layer == i - 1)) {  // x now holds block i-1's output
-            float* dst = hidden_layer < 0 ? hiddens + (size_t)(i - 1) * M * d : hiddens;
-            if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
-                ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
+        {
+            float* cap = i > 0 ? slot(i - 1) : nullptr;  // block i-1's output is formed by this pass
+            TRY(flush_ln(L.ln1_g, L.ln1_b, xn, ESMK_BF16, i > 0 ? (cap ? cap : x) : xc));
         }
         if (w.qparts > 0) {
             // q_ln + rotary of q inside the attention kernel, statistics from the projection's epilogue; k in a k-only pass
@@ -183,7 +193,7 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
             float* gproj = (float*)(ws + w.gproj);
             void* gout = ws + w.gout;
             const int ldg = round_up(3 * vh, 64);
-            TRY(flush_ln(L.geom_ln_g, nullptr, xn, ESMK_BF16));  // dbufA is free again after this pass
+            TRY(flush_ln(L.geom_ln_g, nullptr, xn, ESMK_BF16, xc));  // in place; dbufA is free again after this pass
             TRY(esmk_gemm_ws(xn, d, L.w_geom_proj, M, 15 * vh, d, ESMK_EPI_F32, nullptr, 1.f, gproj, skp, w.splitk_bytes, stream));
             TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
                                b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
@@ -191,18 +201,18 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
             pa = dbufA;
         }
         // --- x += FFN(x) / s  (blocks.py:15-38,154-155)
-        TRY(esmk_add2_layernorm(x, pa, nullptr, 0, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));  // x untouched
+        TRY(esmk_add2_layernorm(xc, pa, nullptr, 0, L.ln2_g, L.ln2_b, xn, ESMK_BF16, M, d, eps, stream));  // stream untouched
         if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
         TRY(esmk_gemm_ws(xn, d, L.w_ffn1, M, 2 * h, d, ESMK_EPI_SWIGLU, nullptr, 1.f, hbuf, skp, w.splitk_bytes, stream));
         if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
         TRY(esmk_gemm_ws(hbuf, h, L.w_ffn2, M, d, h, ESMK_EPI_BF16, nullptr, inv_s, dbufF, skp, w.splitk_bytes, stream));
         pb = dbufF;
     }
-    // final: fold the last delta into x (pre-norm output) and normalise (transformer_stack.py:94)
+    // final: fold the last deltas into the caller's x (pre-norm output) and normalise (transformer_stack.py:94); the
+    // last block's hidden state is the one capture that costs a copy
     void* post = post_norm ? (void*)post_norm : xn;
-    TRY(flush_ln(t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16));
-    if (hiddens && (hidden_layer < 0 || hidden_layer == t->n_layers - 1)) {
-        float* dst = hidden_layer < 0 ? hiddens + (size_t)(t->n_layers - 1) * M * d : hiddens;
+    TRY(flush_ln(t->final_norm_g, nullptr, post, post_norm ? ESMK_F32 : ESMK_BF16, x));
+    if (float* dst = slot(t->n_layers - 1)) {
         if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
             ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
     }

@@ -76,11 +76,11 @@ class DeviceBatch:
     _padded_static: dict = {}
 
     @classmethod
-    def padded(cls, B: int, Ln: int, cu_seqlens: torch.Tensor, device) -> "DeviceBatch":
-        """Batch of a right-padded [B, L] token matrix whose row lengths are known on the DEVICE only
-        (esmk_segments_from_tokens): all B*L positions stay packed, `cu_seqlens` int32 [2B+1] holds (valid prefix,
-        padding) segment pairs, everything else depends on (B, L) alone and is cached per device - building it costs
-        no host synchronisation."""
+    def padded(cls, B: int, Ln: int, cu_seqlens: torch.Tensor, device, positions: torch.Tensor | None = None) -> "DeviceBatch":
+        """Batch of a padded [B, L] token matrix whose row lengths are known on the DEVICE only
+        (esmk_compact_tokens): all B*L positions stay packed, `cu_seqlens` int32 [2B+1] holds (valid tokens,
+        padding) segment pairs and `positions` int32 [B*L] every slot's column; everything else depends on (B, L)
+        alone and is cached per device - building it costs no host synchronisation."""
         device = torch.device(device)
         key = (B, Ln, device.type, device.index if device.index is not None else torch.cuda.current_device())
         st = cls._padded_static.get(key)
@@ -101,6 +101,9 @@ class DeviceBatch:
         d = L.EsmkBatch()
         C.memmove(C.byref(d), C.byref(st.desc), C.sizeof(d))
         d.cu_seqlens = L.ptr(cu_seqlens)
+        if positions is not None:
+            self.positions = positions
+            d.positions = L.ptr(positions)
         d.n_segments = 2 * B
         d.pad_tail = 1
         self.desc = d

@@ -89,10 +89,9 @@ class ESMC(nn.Module):
         return logits, post, hid
 
     def invalid_token_count(self) -> int:
-        """Tokens outside the 64-row table + rows that were not right-padded, summed over the forwards run on the
-        device-described path since the model was built (synchronises; 0 = every input was valid).  Such tokens are
-        clamped into the table, such rows attend over their leading run only - check this where the reference
-        would have raised."""
+        """Tokens outside the 64-row table, summed over the forwards run on the device-described path since the model
+        was built (synchronises; 0 = every input was valid).  Such tokens are clamped into the table - check this
+        where the reference would have raised (or pass validate=True)."""
         return 0 if self._token_err is None else int(self._token_err.item())
 
     # ---- text <-> tokens (reference esmc.py:100-115,175-192) ----------------------------------
@@ -126,9 +125,12 @@ class ESMC(nn.Module):
                            on padding - the form for very ragged batches; esm_amd.pipeline does this for bulk jobs)
         validate           raise IndexError for out-of-range tokens like the reference does (one host synchronisation)
 
-        Default path (sequence_id=None): the batch is described ON THE DEVICE (esmk_segments_from_tokens) - no host
-        synchronisation anywhere in the call; padding positions run through the row-wise kernels, are never attended
-        to, and come back as zeros (the reference's flash path, esmc.py:159-164)."""
+        Default path (sequence_id=None): the batch is described ON THE DEVICE (esmk_compact_tokens) - no host
+        synchronisation anywhere in the call.  Any padding pattern is handled as the reference's
+        `sequence_id = tokens != pad` defines it (the real tokens of a row attend to each other wherever they sit,
+        rotary position = column): real tokens are moved to the front of their row's slots on the way in and back to
+        their columns on the way out (nothing moves in right-padded rows); padding positions run through the row-wise
+        kernels, are never attended to, and come back as zeros (the reference's flash path, esmc.py:159-164)."""
         assert sequence_tokens is not None and sequence_tokens.ndim == 2
         B, Ln = sequence_tokens.shape
         dev = sequence_tokens.device
@@ -143,23 +145,32 @@ class ESMC(nn.Module):
             # ---- device-described batch: no host synchronisation
             if self._token_err is None or self._token_err.device != dev:
                 self._token_err = torch.zeros(1, dtype=torch.int32, device=dev)
-            cu = torch.empty(2 * B + 1, dtype=torch.int32, device=dev)
-            L.check(L.lib().esmk_segments_from_tokens(L.ptr(flat), None, B, Ln, PAD_TOKEN_ID, 64, L.ptr(cu),
-                                                      L.ptr(self._token_err), _stream()), "esmk_segments_from_tokens")
-            batch = DeviceBatch.padded(B, Ln, cu, dev)
-            logits, post, hid = self.forward_packed(flat, batch, want_hiddens=return_hidden_states,
+            # cu [2B+1] | perm [B*L] | positions [B*L] in one int32 buffer; real tokens first in every row's slots
+            n = B * Ln
+            meta = torch.empty(2 * B + 1 + 2 * n, dtype=torch.int32, device=dev)
+            cu, perm, pos = meta[:2 * B + 1], meta[2 * B + 1:2 * B + 1 + n], meta[2 * B + 1 + n:]
+            tok = torch.empty_like(flat)
+            L.check(L.lib().esmk_compact_tokens(L.ptr(flat), B, Ln, PAD_TOKEN_ID, 64, L.ptr(cu), L.ptr(perm), L.ptr(pos),
+                                                L.ptr(tok), L.ptr(self._token_err), _stream()), "esmk_compact_tokens")
+            batch = DeviceBatch.padded(B, Ln, cu, dev, positions=pos)
+            logits, post, hid = self.forward_packed(tok, batch, want_hiddens=return_hidden_states,
                                                     hidden_layer=hidden_layer)
-            pad = (sequence_tokens == PAD_TOKEN_ID).view(B, Ln, 1)
-            if _means is not None:  # means over the valid prefix of every row = the even segments
+            if _means is not None:  # means over the valid tokens of every row = the even segments
                 if _means.get("embedding"):
                     _means["embedding"] = segment_mean(post, cu)[::2]
                 if _means.get("hidden") and hid is not None:
                     _means["hidden"] = torch.stack([segment_mean(hid[i], cu)[::2] for i in range(hid.shape[0])])
+            # slots -> columns, zeros at padding (esmc.py:159-164), in place: nothing moves in right-padded rows
+            unpack = lambda t, n_mat, w: L.check(L.lib().esmk_unpack_rows(L.ptr(t), n_mat, B, Ln, w, L.ptr(perm), L.ptr(cu),
+                                                                         _stream()), "esmk_unpack_rows")
+            unpack(logits, 1, logits.shape[-1])
+            unpack(post, 1, self.d_model)
             hidden = None
             if hid is not None:
-                hidden = hid.view(n_hid, B, Ln, self.d_model).masked_fill_(pad[None], 0.0)
-            return ESMCOutput(sequence_logits=logits.view(B, Ln, -1).masked_fill_(pad, 0.0),
-                              embeddings=post.view(B, Ln, -1).masked_fill_(pad, 0.0), hidden_states=hidden)
+                unpack(hid, n_hid, self.d_model)
+                hidden = hid.view(n_hid, B, Ln, self.d_model)
+            return ESMCOutput(sequence_logits=logits.view(B, Ln, -1), embeddings=post.view(B, Ln, -1),
+                              hidden_states=hidden)
         # ---- host-described batch (explicit sequence_id of any dialect, or drop_pads)
         if sequence_id is None:
             sequence_id = sequence_tokens != PAD_TOKEN_ID  # esmc.py:133-135

@@ -336,11 +336,31 @@ int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, float* x, fl
  * segment 2b = its valid prefix and segment 2b+1 = its padding:
  *     cu_seqlens int32 [2B+1] = {0, len_0, L, L+len_1, 2L, ..., B*L}
  * mask u8 [B, L] (1 = real token) or NULL (then mask = tokens != pad_id).  Use with esmk_batch.pad_tail = 1.
- * err_count int32 [1] (optional, device): incremented by the number of tokens outside [0, vocab) and of rows that
- * are not right-padded (a real token behind a padding position) - the caller reads it when it synchronises anyway.
+ * The valid prefix is the LEADING RUN of real tokens: whatever follows the first padding position counts as padding.
+ * err_count int32 [1] (optional, device): incremented by the number of tokens outside [0, vocab) and of real tokens
+ * that follow a padding position (rows that are not right-padded; esmk_compact_tokens below handles those rows
+ * exactly) - the caller reads it when it synchronises anyway.
  * ------------------------------------------------------------------------------------------ */
 int esmk_segments_from_tokens(const int64_t* tokens, const uint8_t* mask, int B, int L, int64_t pad_id, int vocab,
                               int32_t* cu_seqlens, int32_t* err_count, esmk_stream_t stream);
+
+/* The same for ANY padding pattern - what `sequence_id = sequence_tokens != pad` means in the reference's SDPA path
+ * (esm/models/esmc.py:133-135 with esm/layers/attention.py:65-72: the real tokens of a row attend to each other wherever
+ * they sit, rotary position = column, esm/layers/rotary.py:207-209).  The real tokens of row b are moved to the front of
+ * the row's L slots in their original order (nothing moves in a right-padded row), the padding behind them:
+ *     cu_seqlens int32 [2B+1]  as above (valid tokens of row b, then its padding slots)
+ *     perm       int32 [B*L]   flat source index b*L + column of the token in slot j
+ *     positions  int32 [B*L]   its column (esmk_batch.positions)
+ *     tokens_out int64 [B*L]   the tokens in slot order (must not alias `tokens`)
+ * err_count (optional) counts tokens outside [0, vocab) only.  esmk_unpack_rows is the inverse on the outputs. */
+int esmk_compact_tokens(const int64_t* tokens, int B, int L, int64_t pad_id, int vocab, int32_t* cu_seqlens,
+                        int32_t* perm, int32_t* positions, int64_t* tokens_out, int32_t* err_count, esmk_stream_t stream);
+
+/* Inverse of esmk_compact_tokens on n_mat result matrices x f32 [n_mat][B*L][w], in place: slot j of row b returns to its
+ * source column and padding columns become zero - `pad_input` of the reference's flash path (esm/models/esmc.py:159-164).
+ * w % 4 == 0. */
+int esmk_unpack_rows(float* x, int n_mat, int B, int L, int w, const int32_t* perm, const int32_t* cu_seqlens,
+                     esmk_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * RegressionHead: logits f32 [M, out_dim].  Replaces Linear -> GELU -> LayerNorm -> Linear

@@ -70,20 +70,51 @@ def test_int_sequence_id_with_pads_kept(esmc):
     close(out.embeddings.cpu(), ref["embeddings"])  # all positions, pads included
 
 
-def test_token_range_and_unpadded_rows_are_reported(esmc):
+def test_token_range_is_reported(esmc):
     with pytest.raises(IndexError):
         esmc(torch.tensor([[0, 70, 2]]).cuda(), validate=True)
-    # the default path never synchronises, so it cannot raise: bad tokens / rows are counted on the device
+    # the default path never synchronises, so it cannot raise: bad tokens are counted on the device
     before = esmc.invalid_token_count()
     out = esmc(torch.tensor([[0, 70, 2]]).cuda())
     assert torch.isfinite(out.embeddings).all()
     assert esmc.invalid_token_count() == before + 1
-    tok = synth.synth_tokens([9, 7], pad_to=12, seed=3)
-    tok[1, 3] = 1  # a hole: this row is not right-padded (drop_pads=True handles it, see above)
-    esmc(tok.cuda())
-    assert esmc.invalid_token_count() == before + 2
     esmc(synth.synth_tokens([9, 7], pad_to=12, seed=3).cuda())
-    assert esmc.invalid_token_count() == before + 2
+    assert esmc.invalid_token_count() == before + 1
+
+
+def test_interior_and_left_padding_on_the_default_path(esmc):
+    """Rows that are NOT right-padded (round-2 advisor finding): the reference builds `sequence_id = tokens != pad`
+    (esmc.py:133-135) and masks by equality (attention.py:65-72), so the real tokens attend to each other across the
+    holes and keep their columns as rotary positions.  The default (device-described, sync-free) forward must give
+    exactly that: embeddings, logits and hidden states at every real position against the oracle's dense mask, zeros at
+    the padding positions, and the same answer as the host-described path."""
+    tok = synth.synth_tokens([12, 12, 12, 12], seed=8)
+    tok[0, 3] = 1                      # one hole
+    tok[1, :4] = 1                     # left-padded
+    tok[2, 2:5] = 1; tok[2, 9:] = 1    # holes + right padding
+    tok[3, :] = 1; tok[3, 5] = 7       # a single real token in the middle
+    before = esmc.invalid_token_count()
+    out = esmc(tok.cuda())
+    ref = oracle_esmc(tok)
+    valid = tok != 1
+    close(out.embeddings.cpu()[valid], ref["embeddings"][valid])
+    close(out.sequence_logits.cpu()[valid], ref["sequence_logits"][valid])
+    close(out.hidden_states.cpu()[:, valid], ref["hidden_states"][:, valid])
+    assert out.embeddings.cpu()[~valid].abs().max().item() == 0.0
+    assert out.sequence_logits.cpu()[~valid].abs().max().item() == 0.0
+    assert out.hidden_states.cpu()[:, ~valid].abs().max().item() == 0.0
+    host = esmc(tok.cuda(), drop_pads=True)
+    close(out.embeddings.cpu(), host.embeddings.cpu())
+    assert esmc.invalid_token_count() == before  # holes are not errors
+    # a longer ragged case: 300 columns (two scan chunks of 256), random holes
+    g = torch.Generator().manual_seed(5)
+    tok = synth.synth_tokens([300, 300], seed=9)
+    tok[torch.rand(2, 300, generator=g) < 0.3] = 1
+    out = esmc(tok.cuda(), return_hidden_states=False)
+    ref = oracle_esmc(tok)
+    valid = tok != 1
+    close(out.embeddings.cpu()[valid], ref["embeddings"][valid])
+    assert out.embeddings.cpu()[~valid].abs().max().item() == 0.0
 
 
 def test_noncontiguous_sequence_id_general_equality_mask(esmc):
