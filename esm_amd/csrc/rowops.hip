@@ -18,6 +18,20 @@ int persistent_blocks(K kernel, size_t lds_bytes, int row_groups, int max_per_cu
     return min(row_groups, cus * per_cu);
 }
 
+// The grid cap of a kernel instantiation, remembered PER DEVICE (a process may drive several GPUs; threads may race:
+// every racer computes the same number, the slots are atomics).
+struct DevCap {
+    std::atomic<int> v[64];
+    template <typename F>
+    int get(F compute) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return compute();
+        int c = v[dev].load(std::memory_order_relaxed);
+        if (c == 0) { c = compute(); v[dev].store(c, std::memory_order_relaxed); }
+        return c;
+    }
+};
+
 // --------------------------------------------------------------------------------------------------
 // LayerNorm: one wave per row, the row lives in registers (two-pass mean / variance in fp32).
 // Persistent waves: each wave walks rows wave_id, wave_id + n_waves, ... and issues the loads of its NEXT row
@@ -128,8 +142,8 @@ void launch_layernorm(const void* x, const float* gamma, const float* beta, void
     const size_t lds = (size_t)2 * d * sizeof(float);
 #define LN_LAUNCH(NV)                                                                                                \
     do {                                                                                                             \
-        static int cap = 0; /* resident blocks on the device; measured flat from 2 to 5 per CU, use at most 4 */    \
-        if (cap == 0) cap = persistent_blocks(layernorm_kernel<TIN, TOUT, ADD, NV>, lds, 1 << 30, 4);                \
+        static DevCap dc; /* resident blocks on the device; measured flat from 2 to 5 per CU, use at most 4 */      \
+        const int cap = dc.get([&] { return persistent_blocks(layernorm_kernel<TIN, TOUT, ADD, NV>, lds, 1 << 30, 4); }); \
         hipLaunchKernelGGL((layernorm_kernel<TIN, TOUT, ADD, NV>), dim3(min((M + 3) / 4, cap)), dim3(256), lds, s,   \
                            (const TIN*)x, gamma, beta, (TOUT*)y, M, d, d, eps, (const __bf16*)delta,                 \
                            (const __bf16*)delta2, xw);                                                               \
@@ -608,8 +622,8 @@ extern "C" int esmk_qk_prep_ex(void* qkv, const float* gq, const float* gk, cons
     /* grid = exactly the blocks the device holds at once (3 per CU for 18 heads): measured best */
 #define QK_LAUNCH(NU)                                                                                          \
     do {                                                                                                       \
-        static int cap = 0;                                                                                    \
-        if (cap == 0) cap = persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8);                              \
+        static DevCap dc;                                                                                      \
+        const int cap = dc.get([&] { return persistent_blocks(qk_prep_kernel<NU>, 0, 1 << 30, 8); });          \
         if (ln)                                                                                                \
             hipLaunchKernelGGL((qk_prep_kernel<NU, true>), dim3(min((M + 3) / 4, cap)), block, 0, s, (__bf16*)qkv, gq, \
                                gk, bq, bk, positions, rcos, rsin, rope_len, M, d, H, q_scale, eps); \
@@ -649,8 +663,8 @@ extern "C" int esmk_k_prep(void* qkv, const float* gk, const float* bk, const in
     hipStream_t s = (hipStream_t)stream;
 #define K_LAUNCH(NU)                                                                                           \
     do {                                                                                                       \
-        static int cap = 0;                                                                                    \
-        if (cap == 0) cap = persistent_blocks(k_prep_kernel<NU>, 0, 1 << 30, 8);  /* flat from 2 to 8 per CU */   \
+        static DevCap dc;                                                                                      \
+        const int cap = dc.get([&] { return persistent_blocks(k_prep_kernel<NU>, 0, 1 << 30, 8); });  /* flat from 2 to 8 per CU */ \
         hipLaunchKernelGGL((k_prep_kernel<NU>), dim3(min((M + 7) / 8, cap)), block, 0, s, (__bf16*)qkv, gk, bk,  \
                            positions, rcos, rsin, rope_len, M, d, H, eps, qstats, parts, q_mean_rstd);          \
     } while (0)

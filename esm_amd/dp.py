@@ -164,7 +164,9 @@ def run_data_parallel(sequences: Sequence[torch.Tensor], compute_fn: Callable, w
                     dist.all_gather_into_tensor(recv[slot], send[slot], group=group)
                 else:
                     parts = list(recv[slot].view(world, cap, width).unbind(0)) if rank == 0 else None
-                    dist.gather(send[slot], parts, dst=0, group=group)
+                    # dist.gather's dst is a GLOBAL rank; `rank` above is the rank inside `group`
+                    root = dist.get_global_rank(group, 0) if group is not None else 0
+                    dist.gather(send[slot], parts, dst=root, group=group)
                 if side is not None:
                     done[slot] = torch.cuda.Event()
                     done[slot].record(side)

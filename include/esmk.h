@@ -16,7 +16,8 @@
  *     esmk_gemm_noalloc uses a fixed device array that belongs to the library).
  *   - work is enqueued on `stream` and is ordered with other work on that stream.
  *   - process-wide state: a thread-local error string; per kernel a bit mask of the devices on which its
- *     dynamic-LDS limit has been raised (set once, idempotent); the per-device address of the esmk_gemm_noalloc
+ *     dynamic-LDS limit has been raised (set once, idempotent); per row-wise kernel and device the grid size that
+ *     fills that device (an occupancy query, cached in atomics); the per-device address of the esmk_gemm_noalloc
  *     array.  No environment variable is read by this library (the ESMK_GEMM_* switches exist only in the
  *     separate experiments build, libesmk_x.so).  Entry points are re-entrant across threads and streams unless
  *     their comment says otherwise.

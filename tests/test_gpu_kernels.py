@@ -245,8 +245,8 @@ def _attn_direct_ref(q, k, v, lens):
 
 @pytest.mark.parametrize("profile", ["jump_late", "jump_mid_then_flat", "ramp_up", "ramp_down", "huge_first_tile"])
 def test_attention_score_range_paths(profile):
-    """The attention kernel keeps the first key tile's row maximum as its reference and redoes a block with the textbook
-    running maximum when a row sum leaves the safe range.  Rule: a rare data-dependent path needs inputs that FORCE it
+    """The attention kernel exponentiates the scores without any running maximum (LayerNorm-ed q / k bound them) and
+    redoes a 128-row block with the textbook online softmax when a row sum leaves [2^-100, 2^100].  Rule: a rare data-dependent path needs inputs that FORCE it
     and a full independent reference (fp64 here).  Scores are built as q = e_0 * a_i, k = e_0 * b_j, so s_ij = a_i b_j."""
     H, lens = 2, [300, 64, 700, 1]
     N = sum(lens)

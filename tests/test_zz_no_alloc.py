@@ -23,11 +23,18 @@ def _run(lib, L, engine, M, N, K, epi, seed):
     L.check(lib.esmk_gemm_ws(A.data_ptr(), K, Wp.data_ptr(), M, N, K, epi, bias.data_ptr(), 0.5, ref.data_ptr(),
                              ws.data_ptr(), need, s), "esmk_gemm_ws")
     out = torch.full(shape, float("nan"), dtype=dt, device="cuda")
-    before = torch.cuda.memory_allocated()
-    L.check(lib.esmk_gemm_noalloc(A.data_ptr(), K, Wp.data_ptr(), M, N, K, epi, bias.data_ptr(), 0.5, out.data_ptr(), s),
-            "esmk_gemm_noalloc")
+    call = lambda: L.check(lib.esmk_gemm_noalloc(A.data_ptr(), K, Wp.data_ptr(), M, N, K, epi, bias.data_ptr(), 0.5,
+                                                 out.data_ptr(), s), "esmk_gemm_noalloc")
+    call()  # the documented one warm-up call per device (symbol lookup, LDS attribute)
     torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated() == before
+    out.fill_(float("nan"))
+    torch.cuda.synchronize()
+    # driver-level free bytes: torch.cuda.memory_allocated() only sees torch's caching allocator and would miss a
+    # hipMalloc / hipFree inside the library
+    free_before = torch.cuda.mem_get_info()[0]
+    call()
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free_before
     assert torch.isfinite(out.float()).all()
     assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
     # and against plain fp32 arithmetic, so that "identical" cannot mean "identically wrong"
