@@ -91,6 +91,45 @@ def test_dp_two_ranks_gloo():
         assert shapes == [(s.numel(), WIDTH) for s in seqs]
 
 
+def _subgroup_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        grp = dist.new_group([1, 2])  # a subgroup WITHOUT global rank 0: its root is global rank 1
+        ok = True
+        if rank in (1, 2):
+            seqs = make_sequences()
+            want = [fake_compute(s, [s.numel()]) for s in seqs]
+            for mode in ("root", "all"):
+                res = run_data_parallel(seqs, fake_compute, WIDTH, d=64, h=256, token_budget=80, wire_dtype=torch.float32,
+                                        gather=mode, group=grp)
+                if mode == "all" or rank == 1:
+                    ok = ok and all(torch.allclose(r, w) for r, w in zip(res, want))
+                else:
+                    ok = ok and all(r is None for r in res)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dp_gather_root_inside_a_subgroup():
+    """gather="root" with a process group that does not contain global rank 0 (advisor, round 2): the runner's root is
+    the group's rank 0, and dist.gather must be given its GLOBAL rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=100) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    assert all(ok for _rank, ok in out), out
+
+
 def test_dp_single_process_matches_direct():
     seqs = make_sequences()
     res = run_data_parallel(seqs, fake_compute, WIDTH, d=64, h=256, token_budget=80, wire_dtype=torch.float32)
