@@ -28,14 +28,15 @@ class EsmkEsm3Encoder(C.Structure):
 class EsmkLayer(C.Structure):
     _fields_ = [(n, vp) for n in ("ln1_g", "ln1_b", "w_qkv", "qln_g", "kln_g", "w_o", "ln2_g", "ln2_b", "w_ffn1",
                                   "w_ffn2", "geom_ln_g", "w_geom_proj", "w_geom_out", "geom_dist_scale",
-                                  "geom_rot_scale")]
+                                  "geom_rot_scale", "w_qkv_f", "qkv_u", "qkv_v", "w_ffn1_f", "ffn1_u", "ffn1_v",
+                                  "w_geom_proj_f", "geom_u")]
 
 
 class EsmkTrunk(C.Structure):
     _fields_ = [("d_model", C.c_int), ("n_heads", C.c_int), ("n_layers", C.c_int), ("ffn_hidden", C.c_int),
                 ("v_heads", C.c_int), ("residual_scale", C.c_float), ("layers", C.POINTER(EsmkLayer)),
                 ("final_norm_g", vp), ("rope_cos", vp), ("rope_sin", vp), ("rope_len", C.c_int),
-                ("probe_start", C.POINTER(vp)), ("probe_stop", C.POINTER(vp))]
+                ("probe_start", C.POINTER(vp)), ("probe_stop", C.POINTER(vp)), ("small_tokens", C.c_int)]
 
 
 class EsmkBatch(C.Structure):
@@ -84,6 +85,11 @@ SIGNATURES = {
     "esmk_trunk_forward": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, vp, C.c_size_t, vp]),
     "esmk_trunk_forward_ex": (C.c_int, [C.POINTER(EsmkTrunk), C.POINTER(EsmkBatch), vp, vp, vp, C.c_int, vp, C.c_size_t, vp]),
     "esmk_segments_from_tokens": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp]),
+    "esmk_res_stats_parts": (C.c_int, [C.c_int]),
+    "esmk_row_stats": (C.c_int, [vp, C.c_int, C.c_int, vp, vp, vp]),
+    "esmk_fold_layernorm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
+    "esmk_gemm_lnfold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esmk_gemm_residual_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp]),
     "esmk_compact_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esmk_unpack_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),

@@ -38,9 +38,20 @@ namespace {
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct TrunkWs {
-    size_t xn, qkv, ctx, hbuf, dbuf, dbuf2, gproj, gout, gscratch, splitk, splitk_bytes, qstats, qmr, total;
+    size_t xn, qkv, ctx, hbuf, dbuf, dbuf2, gproj, gout, gscratch, splitk, splitk_bytes, qstats, qmr, rstats, total;
     int qparts;  // > 0: the q side of QK-LayerNorm + rotary runs inside the attention kernel (esmk_attn_varlen_qfused)
 };
+
+// The small-batch path runs when the batch is small enough and every layer carries its LayerNorm-folded weights.
+bool small_path(const esmk_trunk* t, int M) {
+    if (t->small_tokens <= 0 || M > t->small_tokens || esmk_res_stats_parts(t->d_model) > 64) return false;
+    for (int i = 0; i < t->n_layers; ++i) {
+        const esmk_layer& L = t->layers[i];
+        if (!L.w_qkv_f || !L.qkv_u || !L.qkv_v || !L.w_ffn1_f || !L.ffn1_u || !L.ffn1_v) return false;
+        if (L.geom_ln_g && (!L.w_geom_proj_f || !L.geom_u)) return false;
+    }
+    return true;
+}
 
 TrunkWs trunk_layout(const esmk_trunk* t, int M) {
     TrunkWs w{};
@@ -69,6 +80,8 @@ TrunkWs trunk_layout(const esmk_trunk* t, int M) {
     w.qparts = esmk_qkv_stats_parts(M, (int)d);
     w.qstats = off; off += align256((size_t)M * w.qparts * 2 * sizeof(float));
     w.qmr = off; off += align256(w.qparts ? (size_t)M * 2 * sizeof(float) : 0);
+    // small-batch path: per-row partial sums of the residual stream (its bf16 copy lives in xn)
+    w.rstats = off; off += align256(small_path(t, M) ? (size_t)M * esmk_res_stats_parts((int)d) * 2 * sizeof(float) : 0);
     w.total = off;
     return w;
 }
@@ -129,6 +142,66 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
     const float inv_s = 1.0f / t->residual_scale;
     const float q_scale = 0.125f * 1.4426950408889634f;  // 64^-1/2 * log2(e)
     hipStream_t s = (hipStream_t)stream;
+
+    if (small_path(t, M)) {
+        // ---- small-batch path (gemm_sm.hip): x is always current, LayerNorms are folded into the projections that
+        // follow them, residual updates and the next LayerNorm's statistics come out of the producing GEMM's epilogue
+        float* stats = (float*)(ws + w.rstats);
+        void* xb = xn;  // bf16 copy of the stream = the folded projections' operand
+        int parts = 1;
+        const int rparts = esmk_res_stats_parts(d);
+        float* xc = x;
+        auto slot = [&](int layer) -> float* {
+            if (!hiddens || !(hidden_layer < 0 || hidden_layer == layer)) return nullptr;
+            return hidden_layer < 0 ? hiddens + (size_t)layer * M * d : hiddens;
+        };
+        TRY(esmk_row_stats(x, M, d, stats, xb, stream));
+        for (int i = 0; i < t->n_layers; ++i) {
+            const esmk_layer& L = t->layers[i];
+            if (!L.qln_g || !L.kln_g || !L.w_o || !L.w_ffn2)
+                ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d has a null weight", i);
+            // --- x += MHA(x) / s
+            TRY(esmk_gemm_lnfold(xb, d, stats, parts, eps, L.w_qkv_f, L.qkv_u, L.qkv_v, M, 3 * d, d, ESMK_EPI_BF16, qkv, stream));
+            TRY(esmk_qk_prep(qkv, L.qln_g, L.kln_g, b->positions, t->rope_cos, t->rope_sin, t->rope_len, M, d, H, q_scale, eps, stream));
+            TRY(esmk_attn_varlen_impl(qkv, ctx, b->cu_seqlens, b->qblk_map, b->n_qblk, M, d, H, b->pad_tail ? 1 : 0, stream));
+            // reads the stream where the previous block left it (possibly its hiddens slot, which must stay as it is)
+            // and moves it back into the caller's x
+            TRY(esmk_gemm_residual_stats(ctx, d, L.w_o, M, d, d, nullptr, inv_s, xc, x, xb, stats, stream));
+            xc = x;
+            parts = rparts;
+            // --- x += GeomAttn(x) / s
+            if (L.geom_ln_g) {
+                const int vh = t->v_heads;
+                if (vh <= 0 || !L.w_geom_out || !L.geom_dist_scale || !L.geom_rot_scale)
+                    ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: layer %d geometric weights incomplete", i);
+                if (!b->affine || !b->affine_mask || !b->seq_id || !b->chain_id || !b->row_cu)
+                    ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: batch lacks geometric-attention inputs");
+                float* gproj = (float*)(ws + w.gproj);
+                void* gout = ws + w.gout;
+                const int ldg = round_up(3 * vh, 64);
+                TRY(esmk_gemm_lnfold(xb, d, stats, parts, eps, L.w_geom_proj_f, L.geom_u, nullptr, M, 15 * vh, d, ESMK_EPI_F32, gproj, stream));
+                TRY(esmk_geom_attn(gproj, b->affine, b->affine_mask, b->seq_id, b->chain_id, b->row_cu, b->n_rows,
+                                   b->max_row_len, L.geom_dist_scale, L.geom_rot_scale, gout, ldg, ws + w.gscratch, M, vh, stream));
+                TRY(esmk_gemm_residual_stats(gout, ldg, L.w_geom_out, M, d, 3 * vh, nullptr, inv_s, xc, xc, xb, stats, stream));
+            }
+            // --- x += FFN(x) / s
+            if (t->probe_start && t->probe_start[i]) (void)hipEventRecord((hipEvent_t)t->probe_start[i], s);
+            TRY(esmk_gemm_lnfold(xb, d, stats, parts, eps, L.w_ffn1_f, L.ffn1_u, L.ffn1_v, M, 2 * h, d, ESMK_EPI_SWIGLU, hbuf, stream));
+            if (t->probe_stop && t->probe_stop[i]) (void)hipEventRecord((hipEvent_t)t->probe_stop[i], s);
+            // the block's output is formed here: straight into its hiddens slot when captured (the stream lives on there);
+            // the last block always lands in the caller's x
+            float* xo = i + 1 < t->n_layers ? slot(i) : nullptr;
+            if (!xo) xo = x;
+            TRY(esmk_gemm_residual_stats(hbuf, h, L.w_ffn2, M, d, h, nullptr, inv_s, xc, xo, xb, stats, stream));
+            xc = xo;
+        }
+        if (post_norm) TRY(esmk_layernorm(x, ESMK_F32, t->final_norm_g, nullptr, post_norm, ESMK_F32, M, d, eps, stream));
+        if (float* dst = slot(t->n_layers - 1)) {
+            if (hipMemcpyAsync(dst, x, (size_t)M * d * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+                ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_trunk_forward: hidden-state copy failed");
+        }
+        return ESMK_OK;
+    }
 
     // Residual updates travel as bf16 deltas (already scaled by 1/s in the producing GEMM's epilogue) and are
     // folded into the fp32 stream by a later LayerNorm pass, so every big GEMM ends in a coalesced bf16 store.

@@ -115,10 +115,16 @@ class TrunkEngine:
 
     def __init__(self, weights: dict, prefix: str, d_model: int, n_heads: int, n_layers: int, device,
                  v_heads: int | None = None, n_layers_geom: int = 0, scale_residue: bool = True,
-                 expansion_ratio: float = 8 / 3, rope_len: int = 4096):
+                 expansion_ratio: float = 8 / 3, rope_len: int = 4096, small_tokens: int = 1024):
+        """small_tokens: batches of at most this many tokens take the small-batch path of the library (6 launches per
+        block, LayerNorms folded into the projections); its LayerNorm-folded weight copies are built on the first such
+        batch, so a model that only ever sees large batches never holds them.  0 = off."""
         if d_model != 64 * n_heads:
             raise L.EsmkError(f"head dim must be 64 (d_model={d_model}, n_heads={n_heads})")
         self.lib = L.lib()
+        self._src = (weights, prefix, n_layers_geom)
+        self._small_tokens = int(small_tokens) if d_model <= 4096 else 0
+        self._folded = False
         self.device = torch.device(device)
         self.d, self.H, self.n_layers = d_model, n_heads, n_layers
         self.v_heads = v_heads or 0
@@ -168,6 +174,38 @@ class TrunkEngine:
         self._cos, self._sin = cos.to(self.device), sin.to(self.device)
         self._desc.rope_cos, self._desc.rope_sin, self._desc.rope_len = L.ptr(self._cos), L.ptr(self._sin), n_pos
 
+    def _fold_layernorms(self):
+        """W' = W . diag(gamma) (packed), u = W' . 1, v = W . beta for the three projections that follow a LayerNorm
+        (esmk_fold_layernorm): the operands of esmk_gemm_lnfold on the small-batch path."""
+        weights, prefix, n_geom = self._src
+        dev = self.device
+
+        def fold(wname, gname, bname, mode=L.PACK_PLAIN):
+            w = _f32(weights[prefix + wname], dev)
+            g = _f32(weights[prefix + gname], dev)
+            b = _f32(weights[prefix + bname], dev) if bname else None
+            N, K = w.shape
+            wf = torch.empty_like(w)
+            u = torch.empty(N, dtype=torch.float32, device=dev)
+            v = torch.empty(N, dtype=torch.float32, device=dev) if b is not None else None
+            L.check(self.lib.esmk_fold_layernorm(L.ptr(w), L.ptr(g), L.ptr(b), N, K, L.ptr(wf), L.ptr(u), L.ptr(v), _stream()),
+                    "esmk_fold_layernorm")
+            wp = pack_weight(wf, dev, mode)
+            self._keep += [wp, u] + ([v] if v is not None else [])
+            return L.ptr(wp), L.ptr(u), L.ptr(v)
+
+        for i in range(self.n_layers):
+            b = f"blocks.{i}."
+            ly = self._layers[i]
+            ly.w_qkv_f, ly.qkv_u, ly.qkv_v = fold(b + "attn.layernorm_qkv.1.weight", b + "attn.layernorm_qkv.0.weight",
+                                                  b + "attn.layernorm_qkv.0.bias")
+            ly.w_ffn1_f, ly.ffn1_u, ly.ffn1_v = fold(b + "ffn.1.weight", b + "ffn.0.weight", b + "ffn.0.bias", L.PACK_SWIGLU)
+            if i < n_geom:
+                ly.w_geom_proj_f, ly.geom_u, _ = fold(b + "geom_attn.proj.weight", b + "geom_attn.s_norm.weight", None)
+        self._desc.small_tokens = self._small_tokens
+        self._folded = True
+        self._ws = None  # the workspace layout depends on the path
+
     def enable_probes(self, on: bool = True):
         """Record HIP events around every layer's FFN up-projection GEMM (the dominant kernel)."""
         if on and not getattr(self, "_probe_ev", None):
@@ -215,6 +253,8 @@ class TrunkEngine:
         hid = torch.empty((n_hid, N, self.d), dtype=torch.float32, device=x.device) if want_hiddens else None
         if N == 0:
             return post, x, hid
+        if 0 < N <= self._small_tokens and not self._folded:
+            self._fold_layernorms()
         ws = self.workspace(N)
         rc = self.lib.esmk_trunk_forward_ex(C.byref(self._desc), C.byref(batch.desc), L.ptr(x), L.ptr(post), L.ptr(hid),
                                             hidden_layer, L.ptr(ws), ws.numel(), _stream())

@@ -86,6 +86,7 @@ class TransformerStack(nn.Module):
         self.blocks = nn.ModuleList([_Block(d_model, v_heads, i < n_layers_geom, bias, qk_layernorm, ffn_type,
                                             expansion_ratio) for i in range(n_layers)])
         self.norm = nn.LayerNorm(d_model, bias=False)
+        self.small_tokens = 1024  # batches up to this size take the library's small-batch path (0 = never)
         self._engine = None
         self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
 
@@ -103,7 +104,7 @@ class TransformerStack(nn.Module):
             if dev.type != "cuda":
                 raise L.EsmkError("esm_amd runs on the GPU only: move the module to cuda (there is no CPU path)")
             cls = TrunkEngine if self.fused else VariantEngine
-            extra = {} if self.fused else dict(mask_and_zero_frameless=self.mask_and_zero_frameless, bias=self.bias,
+            extra = dict(small_tokens=self.small_tokens) if self.fused else dict(mask_and_zero_frameless=self.mask_and_zero_frameless, bias=self.bias,
                                                qk_layernorm=self.qk_layernorm, ffn_type=self.ffn_type)
             self._engine = cls(dict(self.state_dict()), "", self.d_model, self.n_heads, self.n_layers, dev,
                                v_heads=self.v_heads, n_layers_geom=self.n_layers_geom,

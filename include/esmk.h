@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define ESMK_VERSION 210
+#define ESMK_VERSION 300
 
 #define ESMK_OK 0
 #define ESMK_ERR_INVALID_ARG (-1)
@@ -119,6 +119,34 @@ size_t esmk_gemm_workspace_bytes(int M, int N, int K);
 int esmk_gemm_ws(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, int epilogue,
                  const float* bias, float alpha, void* out, void* workspace, size_t workspace_bytes,
                  esmk_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Small-batch forms (a few hundred to ~1000 tokens: every weight byte is read once from HBM and launches are the cost).
+ *
+ * esmk_gemm_lnfold: out = epilogue(LayerNorm(x) . W^T) with the LayerNorm FOLDED into the projection - the fused
+ * `layernorm_qkv` / `swiglu_ln_ffn` / geometric `s_norm + proj` of the reference (esm/layers/attention.py:26-28,49;
+ * esm/layers/blocks.py:30-33; esm/layers/geom_attention.py:65-72).  LayerNorm is affine per row, so
+ *     LN(x) . W^T = rstd_t * (x . W'^T - mean_t * u) + v,   W' = W . diag(gamma), u = W' . 1, v = W . beta
+ * xb = bf16 copy of the fp32 row x (rounded BEFORE normalisation, as the reference's bf16 path holds its stream);
+ * stats f32 [M][parts][2] = per-row partial (sum, sum of squares) of the FP32 row over d columns, as written by
+ * esmk_gemm_residual_stats (parts = esmk_res_stats_parts(d)) or esmk_row_stats (parts = 1); the kernel reduces them
+ * to mean / rstd in its prologue and applies them, u and v in its epilogue.  W_folded: esmk_pack_weight of the fp32 W'
+ * written by esmk_fold_layernorm (mode SWIGLU for ESMK_EPI_SWIGLU); u, v f32 [N] in the reference's row order
+ * (v may be NULL: no beta).  Epilogues: ESMK_EPI_BF16, ESMK_EPI_F32, ESMK_EPI_SWIGLU.  d %% 64 == 0.
+ *
+ * esmk_gemm_residual_stats: x_out = x_in + alpha * (A . W^T + bias) (blocks.py:146-155; x_out may equal x_in),
+ * xb (optional) = bf16(x_out), stats (optional) = the partial sums above for x_out.  No split-K, no workspace.
+ * esmk_row_stats: stats (parts = 1) and xb of a stream no such epilogue has produced (the embedding output).
+ * ------------------------------------------------------------------------------------------ */
+int esmk_res_stats_parts(int N);
+int esmk_row_stats(const float* x, int M, int d, float* stats, void* xb_bf16, esmk_stream_t stream);
+int esmk_fold_layernorm(const float* w, const float* gamma, const float* beta, int N, int K, float* w_folded, float* u,
+                        float* v, esmk_stream_t stream);
+int esmk_gemm_lnfold(const void* xb_bf16, int lda, const float* stats, int parts, float eps, const void* W_folded_packed,
+                     const float* u, const float* v, int M, int N, int d, int epilogue, void* out, esmk_stream_t stream);
+int esmk_gemm_residual_stats(const void* A_bf16, int lda, const void* W_packed, int M, int N, int K, const float* bias,
+                             float alpha, const float* x_in, float* x_out, void* xb_bf16, float* stats,
+                             esmk_stream_t stream);
 
 /* Allocation-free form of esmk_gemm_ws.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
  * allocate device memory around the call - code under HIP graph capture, tight serving loops, harnesses that
@@ -292,6 +320,12 @@ typedef struct {
     const void* w_geom_proj;                /* packed [15*v_heads, d] */
     const void* w_geom_out;                 /* packed [d, 3*v_heads] */
     const float* geom_dist_scale; const float* geom_rot_scale; /* [v_heads] */
+    /* LayerNorm-folded copies of the three projections that follow a LayerNorm (esmk_fold_layernorm + esmk_pack_weight),
+     * used by the small-batch path (esmk_trunk.small_tokens); all NULL = that path is off for this layer.
+     * w_*_f = packed W . diag(gamma), *_u[n] = sum_k bf16(W'[n,k]), *_v[n] = sum_k W[n,k] beta[k] (reference row order) */
+    const void* w_qkv_f; const float* qkv_u; const float* qkv_v;
+    const void* w_ffn1_f; const float* ffn1_u; const float* ffn1_v;       /* w_ffn1_f packed SWIGLU */
+    const void* w_geom_proj_f; const float* geom_u;                       /* s_norm has no bias: no v */
 } esmk_layer;
 
 typedef struct {
@@ -303,6 +337,10 @@ typedef struct {
     /* optional profiling probes (NULL = off): arrays of n_layers events (esmk_event_create) recorded on `stream`
      * immediately before / after each layer's FFN up-projection GEMM, the dominant kernel of the forward. */
     void* const* probe_start; void* const* probe_stop;
+    /* Batches of at most this many tokens run the small-batch path when every layer carries its folded weights:
+     * 6 launches per block (LayerNorm-folded projections esmk_gemm_lnfold, residual epilogues
+     * esmk_gemm_residual_stats), no split-K partials, no add+LayerNorm passes.  0 = never. */
+    int small_tokens;
 } esmk_trunk;
 
 typedef struct {

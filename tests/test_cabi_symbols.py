@@ -44,7 +44,7 @@ def test_ctypes_table_matches_header():
 
 def test_version_and_host_only_calls():
     lib = _lib.lib()
-    assert lib.esmk_version() == 210
+    assert lib.esmk_version() == 300
     assert re.fullmatch(rb"[0-9a-f]{12}", lib.esmk_build_id())
     assert lib.esmk_packed_weight_bytes(3456, 1152) == 3584 * 1152 * 2  # rows padded to 256
     assert lib.esmk_packed_weight_bytes(11, 24) == 256 * 64 * 2

@@ -23,12 +23,14 @@ def test_padded_batch_equals_single_sequences(model):
     out = model(tok)
     for i, n in enumerate(lens):
         single = model(tok[i:i + 1, :n])
-        # same arithmetic per row, but the small single-sequence problems take the split-K GEMM path (another fp32
-        # summation order before the bf16 roundings) -> bf16-level tolerance on O(1) values, tight cosine
-        assert (out.embeddings[i, :n] - single.embeddings[0]).abs().max().item() <= 4e-2
+        # same arithmetic per row, but the single sequences take the small-batch path (LayerNorms folded into the
+        # projections, fp32 residual epilogues) and the 2048-token batch the large-batch path (bf16 residual deltas,
+        # separate LayerNorm passes): other bf16 rounding points; each is ~1 % in relative L2 from the fp32 oracle
+        # (tools/small_vs_large_parity.py) -> bf16-level tolerance on O(1) values, tight cosine
+        assert (out.embeddings[i, :n] - single.embeddings[0]).abs().max().item() <= 8e-2
         cos = torch.nn.functional.cosine_similarity(out.embeddings[i, :n], single.embeddings[0], dim=-1).min().item()
         assert cos >= 0.9999
-        assert (out.sequence_logits[i, :n] - single.sequence_logits[0]).abs().max().item() <= 4e-2
+        assert (out.sequence_logits[i, :n] - single.sequence_logits[0]).abs().max().item() <= 8e-2
         assert out.embeddings[i, n:].abs().max().item() == 0.0 if n < max(lens) else True
 
 
