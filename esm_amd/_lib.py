@@ -45,6 +45,11 @@ class EsmkBatch(C.Structure):
                 ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int), ("pad_tail", C.c_int)]
 
 
+class EsmkEsm3Inputs(C.Structure):
+    _fields_ = [(n, vp) for n in ("sequence", "structure", "ss8", "sasa", "function_tokens", "residue_tokens",
+                                  "average_plddt", "per_res_plddt")] + [("rows", C.c_int * 8)]
+
+
 class EsmkHead(C.Structure):
     _fields_ = [("w0", vp), ("b0", vp), ("ln_g", vp), ("ln_b", vp), ("w3", vp), ("b3", vp), ("out_dim", C.c_int)]
 
@@ -90,6 +95,7 @@ SIGNATURES = {
     "esmk_fold_layernorm": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp]),
     "esmk_gemm_lnfold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esmk_gemm_residual_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp]),
+    "esmk_esm3_encode_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esmk_compact_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esmk_unpack_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),

@@ -514,6 +514,80 @@ __global__ void esm3_encode_kernel(esmk_esm3_encoder enc, const int64_t* __restr
     out[idx] = acc;
 }
 
+// esm3_encode with the reference's default filling and structure-token fix-ups done here (esm3.py:317-359): a NULL
+// track takes its default, a track with rows == 1 is broadcast over the batch (the reference builds its defaults with
+// batch 1 and lets the sum broadcast), structure tokens are forced at BOS / PAD / EOS / chain-break positions of the
+// sequence track, -1 means MASK.  Out-of-range ids are clamped and counted.
+__global__ void esm3_encode_ex_kernel(esmk_esm3_encoder enc, esmk_esm3_inputs in, float* __restrict__ out, int B, int L,
+                                      int d, int* __restrict__ err) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int M = B * L;
+    if (idx >= (size_t)M * d) return;
+    const int t = (int)(idx / d), c = (int)(idx - (size_t)t * d);
+    const int b = t / L, l = t - b * L;
+    auto at = [&](int track) -> size_t { return (size_t)(in.rows[track] == 1 ? 0 : b) * L + l; };
+    auto oob = [](long long v, int n) -> int { return v < 0 || v >= n; };
+    const long long sq_raw = in.sequence ? in.sequence[at(0)] : 32;  // default: the sequence MASK token
+    const long long sq = clampi(sq_raw, 64);
+    long long st_raw = in.structure ? in.structure[at(1)] : 4096;
+    if (st_raw == -1) st_raw = 4096;                   // STRUCTURE_MASK_TOKEN
+    if (sq_raw == 0) st_raw = 4098;                    // BOS
+    else if (sq_raw == 1) st_raw = 4099;               // PAD
+    else if (sq_raw == 2) st_raw = 4097;               // EOS
+    else if (sq_raw == 31) st_raw = 4100;              // chain break
+    const long long stv = clampi(st_raw, 4101);
+    const long long s8_raw = in.ss8 ? in.ss8[at(2)] : 0, sa_raw = in.sasa ? in.sasa[at(3)] : 0;
+    const long long s8 = clampi(s8_raw, 11), sa = clampi(sa_raw, 19);
+    float acc = enc.sequence_embed[sq * d + c];
+    {
+        const float v = in.average_plddt ? in.average_plddt[at(6)] : 1.0f;
+        float s = enc.plddt_b[c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float z = (v - (float)k * (1.0f / 15.0f)) * 16.0f;
+            s += expf(-z * z) * enc.plddt_w[c * 16 + k];
+        }
+        acc += s;
+    }
+    {
+        const float v = in.per_res_plddt ? in.per_res_plddt[at(7)] : 0.0f;
+        float s = enc.res_plddt_b[c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float z = (v - (float)k * (1.0f / 15.0f)) * 16.0f;
+            s += expf(-z * z) * enc.res_plddt_w[c * 16 + k];
+        }
+        acc += s;
+    }
+    acc += enc.structure_embed[stv * d + c];
+    acc += enc.ss8_embed[s8 * d + c];
+    acc += enc.sasa_embed[sa * d + c];
+    if (in.function_tokens) {
+        const int d8 = d >> 3;
+        const int track = c / d8, cc = c - track * d8;
+        const long long f = clampi(in.function_tokens[at(4) * 8 + track], 260);
+        if (f != 0) acc += enc.function_embed[((size_t)track * 260 + f) * d8 + cc];
+    }
+    if (in.residue_tokens) {
+        float s = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < 16; ++r) {
+            const long long a = clampi(in.residue_tokens[at(5) * 16 + r], 1478);
+            if (a != 0) s += enc.residue_embed[a * d + c];
+        }
+        acc += s;
+    }
+    out[idx] = acc;
+    if (err && c == 0) {  // the thread of channel 0 checks every id of its token
+        int bad = oob(sq_raw, 64) + oob(st_raw, 4101) + oob(s8_raw, 11) + oob(sa_raw, 19);
+        if (in.function_tokens)
+            for (int k = 0; k < 8; ++k) bad += oob(in.function_tokens[at(4) * 8 + k], 260);
+        if (in.residue_tokens)
+            for (int r = 0; r < 16; ++r) bad += oob(in.residue_tokens[at(5) * 16 + r], 1478);
+        if (bad) atomicAdd(err, bad);
+    }
+}
+
 }  // namespace
 
 extern "C" int esmk_layernorm(const void* x, int x_dtype, const float* gamma, const float* beta, void* y, int y_dtype,
@@ -857,6 +931,24 @@ extern "C" int esmk_embed(const int64_t* tokens, const float* table, int vocab, 
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tokens,
                        table, vocab, out, M, d);
     ESMK_CHECK_LAUNCH("esmk_embed");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_esm3_encode_ex(const esmk_esm3_encoder* enc, const esmk_esm3_inputs* in, float* out, int B, int L, int d,
+                                   int32_t* err_count, esmk_stream_t stream) {
+    if (B == 0 || L == 0) return ESMK_OK;
+    if (!enc || !in || !out) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_esm3_encode_ex: null pointer");
+    if (d <= 0 || (d & 7) || B < 0 || L < 0 || (long long)B * L > 0x7fffffffLL)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_esm3_encode_ex: bad sizes (d must be a multiple of 8)");
+    const void* ptrs[8] = {in->sequence, in->structure, in->ss8, in->sasa, in->function_tokens, in->residue_tokens,
+                           in->average_plddt, in->per_res_plddt};
+    for (int i = 0; i < 8; ++i)
+        if (ptrs[i] && in->rows[i] != 1 && in->rows[i] != B)
+            ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_esm3_encode_ex: track %d has %d batch rows, expected 1 or %d", i, in->rows[i], B);
+    const size_t total = (size_t)B * L * d;
+    hipLaunchKernelGGL(esm3_encode_ex_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *enc,
+                       *in, out, B, L, d, err_count);
+    ESMK_CHECK_LAUNCH("esmk_esm3_encode_ex");
     return ESMK_OK;
 }
 

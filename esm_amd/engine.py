@@ -110,6 +110,35 @@ class DeviceBatch:
         return self
 
 
+    _rows_static: dict = {}
+
+    @classmethod
+    def rows(cls, B: int, Ln: int, device, affine=None, affine_mask=None, chain_id=None) -> "DeviceBatch":
+        """Batch of B full rows of Ln tokens with NO sequence_id (every position of a row attends to the whole row,
+        attention.py:73-78) plus this call's geometric-attention inputs.  Everything but those inputs depends on (B, Ln)
+        alone and is cached on the device: building it costs no host work and no synchronisation.  chain_id None = one
+        chain (the zeros ESM3.forward passes, esm3.py:326)."""
+        from .packing import pack_sequence_id
+        device = torch.device(device)
+        key = (B, Ln, device.type, device.index if device.index is not None else torch.cuda.current_device())
+        st = cls._rows_static.get(key)
+        if st is None:
+            if len(cls._rows_static) >= 16:
+                cls._rows_static.pop(next(iter(cls._rows_static)))
+            st = cls(pack_sequence_id(None, B, Ln, drop_false=False), device)
+            st._zero_chain = torch.zeros(B * Ln, dtype=torch.int32, device=device)
+            cls._rows_static[key] = st
+        self = object.__new__(cls)
+        self.__dict__.update(st.__dict__)
+        self.affine, self.affine_mask = affine, affine_mask
+        self.chain_id = st._zero_chain if chain_id is None else chain_id
+        d = L.EsmkBatch()
+        C.memmove(C.byref(d), C.byref(st.desc), C.sizeof(d))
+        d.affine, d.affine_mask, d.chain_id = L.ptr(self.affine), L.ptr(self.affine_mask), L.ptr(self.chain_id)
+        self.desc = d
+        return self
+
+
 class TrunkEngine:
     """Packed TransformerStack weights (reference key names) + esmk_trunk_forward."""
 

@@ -14,7 +14,7 @@ import torch.nn as nn
 from . import _lib as L
 from .affine3d import build_affine3d_from_coordinates
 from .api import ESMProtein, ESMProteinTensor, ForwardTrackData, LogitsConfig, LogitsOutput, _BatchedESMProteinTensor
-from .engine import HeadEngine, _f32, _stream
+from .engine import DeviceBatch, HeadEngine, _f32, _stream
 from .esmc import RegressionHeadParams
 from .transformer_stack import TransformerStack
 
@@ -75,6 +75,7 @@ class ESM3(nn.Module):
         self.function_decoder_fn = function_decoder_fn
         self._structure_encoder = self._structure_decoder = self._function_decoder = None
         self._enc = None
+        self._token_err = None  # device counter of out-of-table ids seen by forward()
         self.register_load_state_dict_post_hook(lambda m, _k: m._invalidate())
 
     def _invalidate(self):
@@ -115,70 +116,78 @@ class ESM3(nn.Module):
     @torch.no_grad()
     def forward(self, *, sequence_tokens=None, structure_tokens=None, ss8_tokens=None, sasa_tokens=None,
                 function_tokens=None, residue_annotation_tokens=None, average_plddt=None, per_res_plddt=None,
-                structure_coords=None, chain_id=None, sequence_id=None, _heads=None) -> ESMOutput:
+                structure_coords=None, chain_id=None, sequence_id=None, _heads=None, validate: bool = False) -> ESMOutput:
         """reference esm3.py:299-374.  _heads (private): names of the output heads to evaluate (default all six);
-        the sampling loop asks for one."""
-        try:
-            Bx, Ln, device = next((x.shape[0], x.shape[1], x.device) for x in
-                                  [sequence_tokens, structure_tokens, ss8_tokens, sasa_tokens, structure_coords,
-                                   function_tokens, residue_annotation_tokens] if x is not None)
-        except StopIteration:
-            raise ValueError("At least one of the inputs must be non-None")
-        B = max(x.shape[0] for x in [sequence_tokens, structure_tokens, ss8_tokens, sasa_tokens, structure_coords,
-                                     function_tokens, residue_annotation_tokens, chain_id, sequence_id]
-                if x is not None)
+        the sampling loop asks for one.
 
-        def defaults(x, tok, dtype=torch.long):
-            return torch.full((1, Ln), tok, dtype=dtype, device=device) if x is None else x
-
-        def bcast(x, tail=()):  # defaults are built with batch 1 in the reference and broadcast in the sum
-            return x.expand(B, Ln, *tail).contiguous()
-
-        sequence_tokens = defaults(sequence_tokens, self.tokenizers.sequence.mask_token_id)
-        ss8_tokens = defaults(ss8_tokens, SS8_PAD_TOKEN)
-        sasa_tokens = defaults(sasa_tokens, SASA_PAD_TOKEN)
-        average_plddt = defaults(average_plddt, 1).float()
-        if average_plddt.ndim == 0:  # ESM3.logits passes a scalar tensor (esm3.py:534)
-            average_plddt = average_plddt.reshape(1, 1).expand(1, Ln)
-        per_res_plddt = defaults(per_res_plddt, 0).float()
-        chain_id = defaults(chain_id, 0)
-        if residue_annotation_tokens is None:
-            residue_annotation_tokens = torch.full((1, Ln, 16), RESIDUE_PAD_TOKEN, dtype=torch.long, device=device)
-        if function_tokens is None:
-            function_tokens = torch.full((1, Ln, 8), INTERPRO_PAD_TOKEN, dtype=torch.long, device=device)
-        if structure_coords is None:
-            structure_coords = torch.full((1, Ln, 3, 3), float("nan"), dtype=torch.float, device=device)
-        structure_coords = structure_coords[..., :3, :]
-        affine, affine_mask = build_affine3d_from_coordinates(bcast(structure_coords, (3, 3)))
-        structure_tokens = defaults(structure_tokens, STRUCTURE_MASK_TOKEN)
-        structure_tokens = (
-            bcast(structure_tokens).masked_fill(bcast(structure_tokens) == -1, STRUCTURE_MASK_TOKEN)
-            .masked_fill(bcast(sequence_tokens) == SEQUENCE_BOS_TOKEN, STRUCTURE_BOS_TOKEN)
-            .masked_fill(bcast(sequence_tokens) == SEQUENCE_PAD_TOKEN, STRUCTURE_PAD_TOKEN)
-            .masked_fill(bcast(sequence_tokens) == SEQUENCE_EOS_TOKEN, STRUCTURE_EOS_TOKEN)
-            .masked_fill(bcast(sequence_tokens) == SEQUENCE_CHAINBREAK_TOKEN, STRUCTURE_CHAINBREAK_TOKEN))
-
-        desc, _keep, heads = self._engines()
-        ranges = ((sequence_tokens, 64, "sequence_tokens"), (structure_tokens, 4101, "structure_tokens"),
-                  (ss8_tokens, 11, "ss8_tokens"), (sasa_tokens, 19, "sasa_tokens"),
-                  (function_tokens, 260, "function_tokens"), (residue_annotation_tokens, 1478, "residue_annotation_tokens"))
-        # one device->host round trip for all twelve bounds (each int(t.min()) would be a synchronisation of its own)
-        bounds = torch.stack([torch.stack((t.min(), t.max())) for t, _n, _name in ranges]).tolist()
-        for (lo, hi), (_t, n, name) in zip(bounds, ranges):
-            if lo < 0 or hi >= n:
-                raise IndexError(f"{name} out of range [0, {n})")
-        M = B * Ln
-        x = torch.empty((M, self.d_model), dtype=torch.float32, device=device)
-        i64 = lambda t, tail=(): bcast(t.to(torch.int64), tail).reshape(M, *tail)
-        f32 = lambda t: bcast(t.to(torch.float32)).reshape(M)
-        args = [i64(sequence_tokens), i64(structure_tokens), f32(average_plddt), f32(per_res_plddt), i64(ss8_tokens),
-                i64(sasa_tokens), i64(function_tokens, (8,)), i64(residue_annotation_tokens, (16,))]
+        The missing-track defaults, the batch-1 broadcasting and the structure-token fix-ups of esm3.py:317-359 happen
+        inside `esmk_esm3_encode_ex`; with sequence_id=None (what `logits()` and the sampler pass) nothing in this call
+        waits for the GPU.  Ids outside their embedding tables are clamped and COUNTED on the device
+        (`invalid_token_count()`); validate=True checks them on the host first and raises IndexError (one synchronisation)."""
         import ctypes as C
-        L.check(L.lib().esmk_esm3_encode(C.byref(desc), *[L.ptr(a) for a in args], L.ptr(x), M, self.d_model,
-                                         _stream()), "esmk_esm3_encode")
-        post, pre, _ = self.transformer(x.view(B, Ln, self.d_model),
-                                        None if sequence_id is None else bcast(sequence_id), affine, affine_mask,
-                                        bcast(chain_id), return_hiddens=False)
+        tracks = (("sequence_tokens", sequence_tokens, 64, ()), ("structure_tokens", structure_tokens, 4101, ()),
+                  ("ss8_tokens", ss8_tokens, 11, ()), ("sasa_tokens", sasa_tokens, 19, ()),
+                  ("function_tokens", function_tokens, 260, (8,)),
+                  ("residue_annotation_tokens", residue_annotation_tokens, 1478, (16,)))
+        shaped = [t for _n, t, _v, _tail in tracks if t is not None] + ([structure_coords] if structure_coords is not None else [])
+        if not shaped:
+            raise ValueError("At least one of the inputs must be non-None")
+        Ln, device = shaped[0].shape[1], shaped[0].device
+        B = max(t.shape[0] for t in shaped + [t for t in (chain_id, sequence_id, per_res_plddt) if t is not None])
+        if device.type != "cuda":
+            raise L.EsmkError("esm_amd runs on the GPU only: pass CUDA tensors (there is no CPU path)")
+        if validate:
+            for name, t, vocab, _tail in tracks:
+                if t is None:
+                    continue
+                lo, hi = int(t.min()), int(t.max())
+                if hi >= vocab or lo < (-1 if name == "structure_tokens" else 0):
+                    raise IndexError(f"{name} out of range [0, {vocab})")
+        desc, _keep, heads = self._engines()
+        if self._token_err is None or self._token_err.device != device:
+            self._token_err = torch.zeros(1, dtype=torch.int32, device=device)
+        M = B * Ln
+        inp = L.EsmkEsm3Inputs()
+        live = []  # keeps converted tensors alive until the launch is enqueued
+
+        def put(i, field, t, dtype, tail):
+            if t is None:
+                return
+            if t.ndim == 0:  # a scalar (reference ESM3.logits passes average_plddt = tensor(1.0)): one row, broadcast
+                t = t.reshape(1, 1).expand(1, Ln)
+            if tuple(t.shape[1:]) != (Ln, *tail) or t.shape[0] not in (1, B):
+                raise ValueError(f"{field}: expected shape [1 or {B}, {Ln}{''.join(', %d' % x for x in tail)}], got {tuple(t.shape)}")
+            t = t.to(device=device, dtype=dtype).contiguous()
+            live.append(t)
+            setattr(inp, field, L.ptr(t))
+            inp.rows[i] = t.shape[0]
+
+        for i, ((_name, t, _v, tail), field) in enumerate(zip(tracks, ("sequence", "structure", "ss8", "sasa",
+                                                                        "function_tokens", "residue_tokens"))):
+            put(i, field, t, torch.int64, tail)
+        put(6, "average_plddt", average_plddt, torch.float32, ())
+        put(7, "per_res_plddt", per_res_plddt, torch.float32, ())
+        x = torch.empty((M, self.d_model), dtype=torch.float32, device=device)
+        L.check(L.lib().esmk_esm3_encode_ex(C.byref(desc), C.byref(inp), L.ptr(x), B, Ln, self.d_model,
+                                            L.ptr(self._token_err), _stream()), "esmk_esm3_encode_ex")
+        # backbone frames (affine3d.py:512-560); no coordinates = no frames anywhere (esm3.py:338-341 fills NaN)
+        if structure_coords is None:
+            structure_coords = torch.full((1, Ln, 3, 3), float("nan"), dtype=torch.float32, device=device)
+        coords = structure_coords[..., :3, :]
+        if coords.shape[0] != B:
+            coords = coords.expand(B, Ln, 3, 3)
+        affine, affine_mask = build_affine3d_from_coordinates(coords)
+        if sequence_id is None:
+            # one segment per row, every position attends everywhere (attention.py:73-78): the batch description
+            # depends on (B, L) alone and is cached on the device - no host work, no synchronisation
+            ch = None if chain_id is None else chain_id.expand(B, Ln).reshape(M).to(torch.int32).contiguous()
+            batch = DeviceBatch.rows(B, Ln, device, affine.tensor.reshape(M, 12), affine_mask.reshape(M).to(torch.uint8), ch)
+            post, pre, _ = self.transformer.engine().forward(x, batch, want_post=True, want_hiddens=False)
+            post, pre = post.view(B, Ln, -1), pre.view(B, Ln, -1)
+        else:
+            cid = torch.zeros((1, Ln), dtype=torch.int64, device=device) if chain_id is None else chain_id
+            post, pre, _ = self.transformer(x.view(B, Ln, self.d_model), sequence_id.expand(B, Ln).contiguous(), affine,
+                                            affine_mask, cid.expand(B, Ln).contiguous(), return_hiddens=False)
         pn = post.reshape(M, self.d_model)
         out = {name: (heads[name].forward(pn).view(B, Ln, -1) if _heads is None or name in _heads else None)
                for name, _ in _HEADS}
@@ -188,6 +197,11 @@ class ESM3(nn.Module):
             secondary_structure_logits=out["ss8_head"], sasa_logits=out["sasa_head"],
             function_logits=None if fl is None else fl.view(B, Ln, 8, 260), residue_logits=out["residue_head"],
             embeddings=pre)
+
+    def invalid_token_count(self) -> int:
+        """Ids outside their embedding tables seen by forward() since the model was built (synchronises; 0 = none).
+        They were clamped into the table - where the reference's embedding lookup would have failed."""
+        return 0 if self._token_err is None else int(self._token_err.item())
 
     def logits(self, input: ESMProteinTensor | _BatchedESMProteinTensor,
                config: LogitsConfig = LogitsConfig()) -> LogitsOutput:
@@ -203,7 +217,8 @@ class ESM3(nn.Module):
         o = self.forward(_heads={k for k, v in want.items() if v},sequence_tokens=input.sequence, structure_tokens=input.structure,
                          ss8_tokens=input.secondary_structure, sasa_tokens=input.sasa, function_tokens=input.function,
                          residue_annotation_tokens=input.residue_annotations,
-                         average_plddt=torch.tensor(1.0, device=input.device), per_res_plddt=per_res_plddt,
+                         average_plddt=None,  # the reference passes 1.0 here, which is also forward()'s default
+                         per_res_plddt=per_res_plddt,
                          structure_coords=input.coordinates, chain_id=None, sequence_id=None)
         return LogitsOutput(
             logits=ForwardTrackData(

@@ -268,6 +268,25 @@ int esmk_esm3_encode(const esmk_esm3_encoder* enc, const int64_t* sequence, cons
                      const int64_t* sasa, const int64_t* function_tokens, const int64_t* residue_tokens,
                      float* out, int M, int d, esmk_stream_t stream);
 
+/* The same with ESM3.forward's default filling and structure-token fix-ups (reference esm/models/esm3.py:317-359) done
+ * in the kernel, so that the Python forward launches one kernel instead of a chain of fill / expand / masked_fill
+ * operations and never synchronises: a NULL track takes the reference's default (sequence MASK 32, structure MASK 4096,
+ * ss8 / sasa / function / residue pad 0, average_plddt 1, per_res_plddt 0); a track with rows == 1 is broadcast over
+ * the B batch rows (esm3.py builds defaults with batch 1); structure tokens: -1 -> MASK, then forced to BOS 4098 /
+ * PAD 4099 / EOS 4097 / chain-break 4100 where the sequence track holds BOS 0 / PAD 1 / EOS 2 / chain-break 31.
+ * rows[i]: batch rows of track i in the order sequence, structure, ss8, sasa, function_tokens, residue_tokens,
+ * average_plddt, per_res_plddt (ignored for NULL tracks).  err_count (optional, device int32): += ids outside their
+ * table (they are clamped), where the reference's embedding lookup would fail. */
+typedef struct {
+    const int64_t* sequence; const int64_t* structure; const int64_t* ss8; const int64_t* sasa; /* [rows, L] */
+    const int64_t* function_tokens;  /* [rows, L, 8] */
+    const int64_t* residue_tokens;   /* [rows, L, 16] */
+    const float* average_plddt; const float* per_res_plddt; /* [rows, L] */
+    int rows[8];
+} esmk_esm3_inputs;
+int esmk_esm3_encode_ex(const esmk_esm3_encoder* enc, const esmk_esm3_inputs* in, float* out, int B, int L, int d,
+                        int32_t* err_count, esmk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Backbone frames.  Replaces build_affine3d_from_coordinates (reference
  * esm/utils/structure/affine3d.py:494-560): Gram-Schmidt frames from (N, CA, C), eps 1e-10,

@@ -252,8 +252,39 @@ def test_esm3_logits_matches_forward_defaults(esm3):
 def test_esm3_requires_an_input_and_checks_ranges(esm3):
     with pytest.raises(ValueError):
         esm3()
+    bad = dict(sequence_tokens=torch.tensor([[0, 5, 2]]).cuda(), ss8_tokens=torch.tensor([[0, 11, 0]]).cuda())
     with pytest.raises(IndexError):
-        esm3(sequence_tokens=torch.tensor([[0, 5, 2]]).cuda(), ss8_tokens=torch.tensor([[0, 11, 0]]).cuda())
+        esm3(validate=True, **bad)
+    # the default call never synchronises, so it cannot raise: out-of-table ids are clamped and counted on the device
+    before = esm3.invalid_token_count()
+    out = esm3(**bad)
+    assert torch.isfinite(out.embeddings).all()
+    assert esm3.invalid_token_count() == before + 1
+    esm3(sequence_tokens=torch.tensor([[0, 5, 2]]).cuda(), structure_tokens=torch.tensor([[-1, 7, 4100]]).cuda())
+    assert esm3.invalid_token_count() == before + 1  # -1 is the reference's "mask me" value, not an error
+
+
+def test_esm3_forward_and_logits_do_not_synchronise(esm3):
+    """ESM3.forward with sequence_id=None (what logits() and the sampler pass): defaults, broadcasting and structure-token
+    fix-ups happen in esmk_esm3_encode_ex, the batch description is cached per (B, L) - nothing waits for the GPU."""
+    L_ = 24
+    seq = synth.synth_tokens([L_, L_], seed=3).cuda()
+    coords = synth.synth_backbone(2, L_, seed=4).cuda()
+    struct = torch.randint(0, 4096, (2, L_)).cuda()
+    pt = ESMProteinTensor(sequence=seq[0], structure=struct[0], coordinates=coords[0])
+    cfg = LogitsConfig(sequence=True, structure=True, return_embeddings=True)
+    want = esm3(sequence_tokens=seq, structure_tokens=struct, structure_coords=coords)  # warm-up: caches, weight packing
+    esm3.logits(pt, cfg)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        got = esm3(sequence_tokens=seq, structure_tokens=struct, structure_coords=coords)
+        lg = esm3.logits(pt, cfg)
+        one = esm3(sequence_tokens=seq[:1])  # every other track at its default
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.equal(got.embeddings, want.embeddings) and torch.equal(got.structure_logits, want.structure_logits)
+    assert lg.logits.sequence.shape == (1, L_, 64) and one.sequence_logits.shape == (1, L_, 64)
 
 
 def test_state_dict_reload_repacks_weights(esmc):
