@@ -96,6 +96,8 @@ SIGNATURES = {
     "esmk_gemm_lnfold": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_float, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp]),
     "esmk_gemm_residual_stats": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, C.c_float, vp, vp, vp, vp, vp]),
     "esmk_esm3_encode_ex": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "esmk_sampling_mask": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, C.c_int64, C.c_int, vp, vp]),
+    "esmk_sample_sasa": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esmk_compact_tokens": (C.c_int, [vp, C.c_int, C.c_int, C.c_int64, C.c_int, vp, vp, vp, vp, vp, vp]),
     "esmk_unpack_rows": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "esmk_segment_mean": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, C.c_int, vp]),

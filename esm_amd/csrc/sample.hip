@@ -125,6 +125,52 @@ __global__ __launch_bounds__(64) void sample_track_kernel(float* __restrict__ lo
     }
 }
 
+// Which positions of a [B, L] token matrix the sampler may overwrite (one thread per position).
+struct SpecialIds { int n; long long id[64]; };
+__global__ void sampling_mask_kernel(const int64_t* __restrict__ tokens, int B, int L, SpecialIds sp, long long mask_id,
+                                     int only_masked, uint8_t* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * L) return;
+    const int col = i % L;
+    const long long t = tokens[i];
+    bool on = col != 0 && col != L - 1;          // never the BOS / EOS columns
+    for (int k = 0; k < sp.n; ++k) on = on && t != sp.id[k];  // nor a special token (the mask id is not in the list)
+    if (only_masked) on = on && t == mask_id;
+    out[i] = on ? 1 : 0;
+}
+
+// SASA is decoded to a number, not a class: expectation of the bin mid-points under softmax(logits) over the value bins
+// (classes 3 .. V-2; class V-1 is the open last bin).  One thread per row; V is small (19).
+__global__ void sample_sasa_kernel(float* __restrict__ logits, int R, int V, int L, const uint8_t* __restrict__ valid,
+                                   const float* __restrict__ bin_mid, const uint8_t* __restrict__ smask,
+                                   float* __restrict__ value, float* __restrict__ entropy) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float* l = logits + (size_t)r * V;
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int v = 0; v < V; ++v) {
+        if (valid && !valid[v]) l[v] = -INFINITY;  // in place, as the reference edits its logits
+        if (l[v] > mx) { mx = l[v]; arg = v; }     // first maximum, like torch.argmax
+    }
+    float z = 0.f;
+    for (int v = 0; v < V; ++v) z += expf(l[v] - mx);
+    const float logz = logf(z);
+    float mean = 0.f, ent = 0.f;
+    for (int v = 0; v < V; ++v) {
+        const float lp = (l[v] - mx) - logz, p = expf(lp);
+        if (v >= 3 && v < V - 1) mean += p * bin_mid[v - 3];
+        const float pl = p * lp;                   // 0 * -inf is NaN: torch.nan_to_num turns it into 0
+        ent -= (pl != pl) ? 0.f : pl;
+    }
+    const int col = r % L;
+    float out = mean;
+    if (arg == V - 1 || (smask && !smask[r])) out = INFINITY;  // open last bin / position not sampled: no number
+    if (col == 0 || col == L - 1) out = 0.f;                   // BOS / EOS columns
+    value[r] = out;
+    entropy[r] = ent;
+}
+
 }  // namespace
 
 extern "C" int esmk_sample_track(float* logits, int R, int V, const uint8_t* valid, float temperature, float top_p,
@@ -142,5 +188,31 @@ extern "C" int esmk_sample_track(float* logits, int R, int V, const uint8_t* val
                        valid, temperature, top_p, temperature > 0.f ? noise : nullptr, tokens, sampling_mask, sampled,
                        entropy, logprob, top_prob);
     ESMK_CHECK_LAUNCH("esmk_sample_track");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_sampling_mask(const int64_t* tokens, int B, int L, const int64_t* special_ids, int n_special,
+                                  int64_t mask_id, int only_sample_masked, uint8_t* out, esmk_stream_t stream) {
+    if (B == 0 || L == 0) return ESMK_OK;
+    if (!tokens || !out || (n_special > 0 && !special_ids)) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_sampling_mask: null pointer");
+    if (B < 0 || L < 0 || n_special < 0 || n_special > 64 || (long long)B * L > 0x7fffffffLL)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_sampling_mask: bad sizes (at most 64 special ids)");
+    SpecialIds sp{};
+    for (int i = 0; i < n_special; ++i)
+        if (special_ids[i] != mask_id) sp.id[sp.n++] = special_ids[i];  // HOST array: copied into the launch
+    hipLaunchKernelGGL(sampling_mask_kernel, dim3((B * L + 255) / 256), dim3(256), 0, (hipStream_t)stream, tokens, B, L, sp,
+                       (long long)mask_id, only_sample_masked, out);
+    ESMK_CHECK_LAUNCH("esmk_sampling_mask");
+    return ESMK_OK;
+}
+
+extern "C" int esmk_sample_sasa(float* logits, int R, int V, int L, const uint8_t* valid, const float* bin_mid,
+                                const uint8_t* sampling_mask, float* value, float* entropy, esmk_stream_t stream) {
+    if (R == 0) return ESMK_OK;
+    if (!logits || !bin_mid || !value || !entropy) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_sample_sasa: null pointer");
+    if (R < 0 || V < 5 || V > 4096 || L <= 0 || (R % L)) ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_sample_sasa: bad sizes (R = B * L rows, V >= 5)");
+    hipLaunchKernelGGL(sample_sasa_kernel, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, R, V, L, valid,
+                       bin_mid, sampling_mask, value, entropy);
+    ESMK_CHECK_LAUNCH("esmk_sample_sasa");
     return ESMK_OK;
 }

@@ -95,17 +95,19 @@ def annealed_temperature(step: int, num_steps: int, initial_temperature: float) 
 
 
 def get_sampling_mask(tokens: torch.Tensor, config: SamplingTrackConfig, mask_idx: int) -> torch.Tensor:
-    """sampling.py:322-343: never BOS / EOS columns or special tokens other than MASK; only masks if asked."""
-    m = torch.ones_like(tokens, dtype=torch.bool)
-    m[:, 0] = False
-    m[:, -1] = False
-    special = sorted(set(int(i) for i in config.invalid_ids) - {mask_idx})
-    if special:
-        sp = torch.tensor(special, device=tokens.device)
-        m &= (tokens[..., None] != sp[None, :]).all(-1)
-    if config.only_sample_masked_tokens:
-        m &= tokens == mask_idx
-    return m
+    """Positions the sampler may overwrite, bool [B, L] (reference sampling.py:321-342): `esmk_sampling_mask`."""
+    import ctypes as C
+    assert tokens.is_cuda and tokens.ndim == 2
+    B, Ln = tokens.shape
+    tok = tokens.to(torch.int64).contiguous()
+    ids = sorted(set(int(i) for i in config.invalid_ids))
+    if len(ids) > 64:
+        raise ValueError("at most 64 special ids")
+    host = (C.c_int64 * max(len(ids), 1))(*ids)
+    out = torch.empty((B, Ln), dtype=torch.uint8, device=tokens.device)
+    L.check(L.lib().esmk_sampling_mask(L.ptr(tok), B, Ln, host, len(ids), int(mask_idx),
+                                       1 if config.only_sample_masked_tokens else 0, L.ptr(out), _stream()), "esmk_sampling_mask")
+    return out.bool()
 
 
 def sample_track(logits: torch.Tensor, tokens: torch.Tensor, config: SamplingTrackConfig, mask_idx: int,
@@ -145,26 +147,32 @@ def sample_track(logits: torch.Tensor, tokens: torch.Tensor, config: SamplingTra
     return out
 
 
+_SASA_MID: dict = {}
+
+
 def sample_sasa_logits(logits: torch.Tensor, tokens: torch.Tensor, config: SamplingTrackConfig, mask_idx: int,
                        valid_ids: Sequence[int], mask_logits_of_invalid_ids: bool = True):
-    """SASA is decoded to a float per residue: the probability-weighted mean of the bin mid-points
-    (sampling.py:255-290; entropy: generation.py:631-639).  [B, L, 19] logits, edited in place like the reference.
-    Returns (sasa_value [B, L], entropy [B, L]).  Plain tensor ops: 19 classes, not a hot spot."""
+    """SASA comes back as a float per residue (reference sampling.py:255-290; entropy generation.py:631-639):
+    `esmk_sample_sasa` on the [B, L, 19] logits, which are edited in place like the reference's.
+    Returns (sasa_value [B, L], entropy [B, L])."""
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.is_contiguous() and logits.ndim == 3
+    B, Ln, V = logits.shape
+    dev = logits.device
+    mid = _SASA_MID.get(dev)
+    if mid is None:  # mid-points of the value bins [0, b_0), [b_0, b_1), ...
+        edges = torch.tensor([0.0] + list(SASA_DISCRETIZATION_BOUNDARIES), dtype=torch.float32)
+        mid = _SASA_MID[dev] = ((edges[1:] + edges[:-1]) * 0.5).to(dev)
+    assert mid.numel() == V - 4
+    valid = None
     if mask_logits_of_invalid_ids:
-        m = torch.ones_like(logits, dtype=torch.bool)
-        m[..., list(valid_ids)] = False
-        logits[m] = -torch.inf
-    probs = torch.softmax(logits, dim=-1)
-    max_idx = torch.argmax(probs, dim=-1)
-    bins = torch.tensor([0] + SASA_DISCRETIZATION_BOUNDARIES, dtype=torch.float)
-    bins = ((bins[:-1] + bins[1:]) / 2).to(probs.device)
-    smask = get_sampling_mask(tokens, config, mask_idx)
-    value = torch.sum(probs[..., 3:-1] * bins, dim=-1)
-    value[max_idx == 18] = float("inf")
-    value[~smask] = float("inf")
-    value[..., 0] = 0.0
-    value[..., -1] = 0.0
-    entropy = -(torch.nan_to_num(probs * logits.log_softmax(-1))).sum(-1)
+        valid = torch.zeros(V, dtype=torch.uint8)
+        valid[list(valid_ids)] = 1
+        valid = valid.to(dev)
+    smask = get_sampling_mask(tokens, config, mask_idx).to(torch.uint8)
+    value = torch.empty((B, Ln), dtype=torch.float32, device=dev)
+    entropy = torch.empty((B, Ln), dtype=torch.float32, device=dev)
+    L.check(L.lib().esmk_sample_sasa(L.ptr(logits), B * Ln, V, Ln, L.ptr(valid), L.ptr(mid), L.ptr(smask), L.ptr(value),
+                                     L.ptr(entropy), _stream()), "esmk_sample_sasa")
     return value, entropy
 
 

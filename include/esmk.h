@@ -465,6 +465,20 @@ int esmk_sample_track(float* logits, int R, int V, const uint8_t* valid, float t
                       const float* noise, const int64_t* tokens, const uint8_t* sampling_mask, int64_t* sampled,
                       float* entropy, float* logprob, float* top_prob, esmk_stream_t stream);
 
+/* Which positions the sampler may overwrite (esm/utils/sampling.py:321-342): tokens int64 [B, L] -> out u8 [B, L] = 1 except
+ * in the first / last column (BOS / EOS), where the token is one of `special_ids` (a HOST array of at most 64 ids; an
+ * entry equal to mask_id is ignored) and, with only_sample_masked, where the token is not mask_id. */
+int esmk_sampling_mask(const int64_t* tokens, int B, int L, const int64_t* special_ids_host, int n_special,
+                       int64_t mask_id, int only_sample_masked, uint8_t* out, esmk_stream_t stream);
+
+/* SASA decoding (esm/utils/sampling.py:260-290; entropy esm/utils/generation.py:631-639): logits f32 [R = B*L, V]
+ * (V = 19: 3 special classes, V-4 value bins, one open last bin), edited in place (classes with valid[v] == 0 -> -inf).
+ * value[r] = sum over the value bins of softmax(logits)[3 + k] * bin_mid[k] (bin_mid f32 [V-4], device); +inf where the
+ * arg-max is the open last bin or sampling_mask[r] == 0 (optional mask); 0 in the first / last column of a row of L.
+ * entropy[r] = -sum p log p of softmax(logits), 0 * -inf counted as 0. */
+int esmk_sample_sasa(float* logits, int R, int V, int L, const uint8_t* valid, const float* bin_mid,
+                     const uint8_t* sampling_mask, float* value, float* entropy, esmk_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Output side of the VQ-VAE structure decoder (StructureTokenDecoder.decode, reference
  * esm/models/vqvae.py:365-437).  The decoder stack itself is esmk_trunk_forward (residual_scale = 1,

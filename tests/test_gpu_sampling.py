@@ -31,6 +31,44 @@ def test_sample_track_matches_reference(i):
         np.testing.assert_allclose(out[name].cpu().numpy(), G[k + name], rtol=1e-4, atol=tol, err_msg=name)
 
 
+def test_sampling_mask_kernel_matches_reference_semantics():
+    """esmk_sampling_mask (reference sampling.py:321-342) against a plain restatement and the reference's own outputs:
+    positions the reference left untouched are exactly the unmasked ones."""
+    from esm_amd.sampling import SamplingTrackConfig, get_sampling_mask
+    for i in range(int(G["n_sample_track"])):
+        k = f"st{i}_"
+        tokens = torch.from_numpy(G[k + "tokens"])
+        inv, mask_idx, only = G[k + "invalid_ids"].tolist(), int(G[k + "mask_idx"]), bool(G[k + "only_masked"])
+        cfg = SamplingTrackConfig(invalid_ids=inv, only_sample_masked_tokens=only)
+        m = get_sampling_mask(tokens.cuda(), cfg, mask_idx).cpu()
+        want = torch.ones_like(tokens, dtype=torch.bool)
+        want[:, 0] = want[:, -1] = False
+        for s_ in set(inv) - {mask_idx}:
+            want &= tokens != s_
+        if only:
+            want &= tokens == mask_idx
+        assert torch.equal(m, want)
+        changed = torch.from_numpy(G[k + "sampled"]) != tokens
+        assert not (changed & ~m).any()
+
+
+def test_sasa_decoding_kernel_matches_reference():
+    """esmk_sample_sasa against the outputs of the reference's sample_sasa_logits (sampling.py:260-290) and its entropy
+    (generation.py:631-639) stored in tests/golden/sampling.npz."""
+    from esm_amd.sampling import SamplingTrackConfig, sample_sasa_logits
+    lg = torch.from_numpy(G["sasa_logits"]).clone().cuda().contiguous()
+    val, ent = sample_sasa_logits(lg, torch.from_numpy(G["sasa_tokens"]).cuda(), SamplingTrackConfig(), 0, G["sasa_valid"].tolist())
+    val, ent = val.cpu(), ent.cpu()
+    want = torch.from_numpy(G["sasa_value"])
+    assert torch.equal(torch.isinf(val), torch.isinf(want))
+    fin = torch.isfinite(want)
+    torch.testing.assert_close(val[fin], want[fin], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(ent, torch.from_numpy(G["sasa_entropy"]), rtol=1e-5, atol=1e-5)
+    # invalid classes were masked in place, like the reference's logits
+    bad = [v for v in range(lg.shape[-1]) if v not in G["sasa_valid"].tolist()]
+    assert torch.isneginf(lg[..., bad]).all()
+
+
 def test_sample_track_errors_and_device_noise():
     from esm_amd._lib import EsmkError
     from esm_amd.sampling import SamplingTrackConfig, sample_track

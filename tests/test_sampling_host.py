@@ -1,12 +1,12 @@
-"""Host logic of the sampling loop (CPU): step masks, annealing and sampling masks against fixtures produced by
-the reference's generation.py / sampling.py (oracle/make_golden.py sampling_cases)."""
+"""Host logic of the sampling loop (CPU): step masks and annealing against fixtures produced by the reference's
+generation.py / sampling.py (oracle/make_golden.py sampling_cases).  The sampling mask and the SASA decoding are device
+kernels: tests/test_gpu_sampling.py."""
 import os
 
 import numpy as np
 import torch
 
-from esm_amd.sampling import (GenerationConfig, SamplingTrackConfig, annealed_temperature, choose_positions,
-                              get_sampling_mask, step_unmask_count)
+from esm_amd.sampling import GenerationConfig, annealed_temperature, choose_positions, step_unmask_count
 
 G = np.load(os.path.join(os.path.dirname(__file__), "golden", "sampling.npz"))
 
@@ -49,18 +49,6 @@ def test_choose_positions_random_counts():
     assert where.sum(-1).tolist() == [7, 3, 0] and not (where & ~cand).any()
 
 
-def test_sampling_mask_matches_reference_semantics():
-    for i in range(int(G["n_sample_track"])):
-        k = f"st{i}_"
-        tokens = torch.from_numpy(G[k + "tokens"])
-        cfg = SamplingTrackConfig(invalid_ids=G[k + "invalid_ids"].tolist(), only_sample_masked_tokens=bool(G[k + "only_masked"]))
-        m = get_sampling_mask(tokens, cfg, int(G[k + "mask_idx"]))
-        # positions the reference left untouched are exactly the unmasked ones
-        changed = torch.from_numpy(G[k + "sampled"]) != tokens
-        assert not (changed & ~m).any()
-        assert not m[:, 0].any() and not m[:, -1].any()
-
-
 def test_generation_config_validation():
     import pytest
     with pytest.raises(ValueError):
@@ -70,14 +58,3 @@ def test_generation_config_validation():
     c = GenerationConfig(track="sequence")
     c.use_entropy_based_unmasking_strategy()
     assert (c.schedule, c.strategy, c.temperature_annealing) == ("cosine", "entropy", False)
-
-
-def test_sasa_decoding_matches_reference():
-    from esm_amd.sampling import sample_sasa_logits
-    lg = torch.from_numpy(G["sasa_logits"]).clone()
-    val, ent = sample_sasa_logits(lg, torch.from_numpy(G["sasa_tokens"]), SamplingTrackConfig(), 0, G["sasa_valid"].tolist())
-    want = torch.from_numpy(G["sasa_value"])
-    assert torch.equal(torch.isinf(val), torch.isinf(want))
-    fin = torch.isfinite(want)
-    torch.testing.assert_close(val[fin], want[fin], rtol=1e-6, atol=1e-6)
-    torch.testing.assert_close(ent, torch.from_numpy(G["sasa_entropy"]), rtol=1e-6, atol=1e-6)
