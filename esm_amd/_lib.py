@@ -42,7 +42,8 @@ class EsmkTrunk(C.Structure):
 class EsmkBatch(C.Structure):
     _fields_ = [("n_tokens", C.c_int), ("n_segments", C.c_int), ("cu_seqlens", vp), ("positions", vp),
                 ("qblk_map", vp), ("n_qblk", C.c_int), ("affine", vp), ("affine_mask", vp), ("seq_id", vp),
-                ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int), ("pad_tail", C.c_int)]
+                ("chain_id", vp), ("row_cu", vp), ("n_rows", C.c_int), ("max_row_len", C.c_int), ("pad_tail", C.c_int),
+                ("max_position", C.c_int)]
 
 
 class EsmkEsm3Inputs(C.Structure):

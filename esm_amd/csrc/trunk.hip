@@ -128,6 +128,9 @@ extern "C" int esmk_trunk_forward_ex(const esmk_trunk* t, const esmk_batch* b, f
     if (M == 0) return ESMK_OK;
     if (!b->cu_seqlens || !b->positions || !b->qblk_map || b->n_qblk <= 0)
         ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: batch lacks cu_seqlens/positions/qblk_map");
+    if (b->max_position < 0 || b->max_position >= t->rope_len)
+        ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_trunk_forward: batch max_position %d outside the rotary tables (rope_len %d)",
+                  b->max_position, t->rope_len);
     const TrunkWs w = trunk_layout(t, M);
     if (!workspace || workspace_bytes < w.total)
         ESMK_FAIL(ESMK_ERR_WORKSPACE, "esmk_trunk_forward: workspace %zu < required %zu", workspace_bytes, w.total);

@@ -71,6 +71,7 @@ class DeviceBatch:
         d.n_rows = pb.B
         d.max_row_len = pb.max_row_len
         d.pad_tail = 0
+        d.max_position = int(pb.max_position)
         self.desc = d
 
     _padded_static: dict = {}

@@ -170,7 +170,9 @@ int esmk_gemm_noalloc(const void* A_bf16, int lda, const void* W_packed, int M, 
  * 64-wide head (reference attention.py:31-33,40-46,51-55; rotary.py:36-65,198-230) and, for the
  * packed layout, flash-attn's Triton apply_rotary (rotary.py:246-261).
  * qkv bf16 [M, 3d]: columns [0,d)=q, [d,2d)=k, [2d,3d)=v (attention.py:50), head h = columns h*64..h*64+63.
- * positions int32 [M]: rotary position of each token (column index in the reference's [B,L] row).
+ * positions int32 [M]: rotary position of each token (column index in the reference's [B,L] row).  PRECONDITION (also of
+ * esmk_k_prep and esmk_attn_varlen_qfused): 0 <= positions[i] < rope_len - the values are device data the host cannot
+ * see, a larger one reads the table's last row.  esmk_trunk_forward checks esmk_batch.max_position against rope_len.
  * rope_cos / rope_sin f32 [rope_len, 32] (angles computed in fp32 as rotary.py:136-181 does).
  * q is additionally multiplied by q_scale (softmax scale * log2(e)) so the attention kernel uses exp2.
  * gamma_q = gamma_k = NULL: the qk_layernorm=False block variant (attention.py:34-38: q_ln / k_ln are Identity) -
@@ -374,6 +376,9 @@ typedef struct {
     /* 1: the layout of esmk_segments_from_tokens - segments come in (valid prefix, padding) pairs per padded row and
      * qblk_map holds, per row, blocks (segment 2b, q0) for q0 = 0, 128, ... < L; attention output of padding rows is 0 */
     int pad_tail;
+    /* largest value in `positions` (host-side knowledge of whoever built them).  esmk_trunk_forward rejects a batch
+     * whose max_position >= esmk_trunk.rope_len with ESMK_ERR_INVALID_ARG instead of reading past the rotary tables. */
+    int max_position;
 } esmk_batch;
 
 size_t esmk_trunk_workspace_bytes(const esmk_trunk* t, int n_tokens);
