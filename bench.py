@@ -24,7 +24,7 @@ Extra objects on the line:
   roofline      dominant kernel = the FFN up-projection GEMM with the SwiGLU epilogue: algorithmic FLOPs / mean launch
                 time from HIP events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak
                 (MI355X_MICROARCH.md).  `traffic` (HBM-side bytes per launch) is read from the PMC profile
-                profiles/r02_pmc_bench.json when that profile was taken with THIS binary (esmk_build_id), else null.
+                profiles/r03_pmc_bench.json when that profile was taken with THIS binary (esmk_build_id), else null.
   cpu_baseline  the CPU oracle (fp32 restatement of the reference, oracle/trunk_ref.py) timed on this host's
                 cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -45,7 +45,7 @@ if ROOT not in sys.path:
 D_MODEL, N_HEADS, N_LAYERS, FFN_H = 1152, 18, 36, 3072
 BATCH, SEQ_LEN = 64, 512
 PEAK_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_bench.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_bench.json")
 C4_SEQS, C4_LMIN, C4_LMAX, C4_SEED, C4_BUDGET = 4096, 64, 2048, 7, 32768
 
 
@@ -107,7 +107,7 @@ def time_dominant_kernel(model, tokens, batch, steps=3):
 
 
 def measured_counters(build_id: str, workload: str):
-    """PMC figures of the dominant kernel from profiles/r02_pmc_bench.json, only when that profile was taken with
+    """PMC figures of the dominant kernel from profiles/r03_pmc_bench.json, only when that profile was taken with
     the binary that is running now and on this workload; otherwise (None, reason)."""
     try:
         prof = json.load(open(PMC_PROFILE))
@@ -117,7 +117,7 @@ def measured_counters(build_id: str, workload: str):
         return None, f"PMC profile is from build {prof.get('build_id')}, this binary is {build_id}"
     if prof.get("config") != workload:
         return None, f"PMC profile is for config {prof.get('config')}"
-    return prof, "profiles/r02_pmc_bench.json (rocprofv3 --pmc, separate passes, this binary)"
+    return prof, "profiles/r03_pmc_bench.json (rocprofv3 --pmc, separate passes, this binary)"
 
 
 def cpu_baseline(weights, n_seqs=6):
@@ -386,6 +386,17 @@ def main():
             torch.cuda.synchronize()
             line["api_residues_per_s"] = 5 * n_tok / (time.perf_counter() - ta)
             line["api_note"] = "ESMC.logits(_BatchedESMProteinTensor[64, 512], LogitsConfig(sequence, return_embeddings)), 5 calls, one GPU"
+            # the reference's DEFAULT forward also returns all 36 hidden states (esmc.py:167): [36, 64, 512, 1152] fp32 =
+            # 5.4 GB per call, written by the residual-stream pass itself (no copies) and un-padded in place
+            for _ in range(2):
+                model(tokens.view(BATCH, SEQ_LEN))
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(5):
+                model(tokens.view(BATCH, SEQ_LEN))
+            torch.cuda.synchronize()
+            line["api_hidden_states_residues_per_s"] = 5 * n_tok / (time.perf_counter() - ta)
+            line["api_hidden_states_note"] = "ESMC.forward(tokens[64, 512]) with return_hidden_states=True (the reference's default), 5 calls"
         if args.config == "c4":
             line["dp"] = stats
         if world == 1 and not args.no_cpu_baseline:

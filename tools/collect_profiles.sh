@@ -1,8 +1,8 @@
-# Round-2 profiles of the headline bench (run on the GPU box from the repo root):  bash tools/collect_profiles.sh
+# Profiles of the headline bench (run on the GPU box from the repo root):  bash tools/collect_profiles.sh
 #   1. rocprofv3 --kernel-trace --stats over bench.py          -> gpurun_out/prof/bench_kernel_stats.csv
 #   2. three separate --pmc passes over bench.py (never mixed with tracing; <= 4 TCC / 8 SQ / 2 GRBM counters per pass)
-#   3. tools/pmc_bench_parse.py                                 -> gpurun_out/prof/r02_pmc_bench.json (carries esmk_build_id)
-# Copy the two result files into profiles/ afterwards (bench.py reads profiles/r02_pmc_bench.json).
+#   3. tools/pmc_bench_parse.py                                 -> gpurun_out/prof/r03_pmc_bench.json (carries esmk_build_id)
+# Copy the two result files into profiles/ afterwards (bench.py reads profiles/r03_pmc_bench.json).
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
@@ -12,4 +12,4 @@ timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o p --output-f
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d $OUT/pmc_write -o p --output-format csv -- python3 $B > $OUT/pmc_write.log 2>&1 || { echo "WRITE_SIZE pass failed"; exit 1; }
 timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $OUT/pmc_sq -o p --output-format csv -- python3 $B > $OUT/pmc_sq.log 2>&1 || { echo "SQ pass failed"; exit 1; }
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -n 1) $OUT/bench_kernel_stats.csv
-python3 tools/pmc_bench_parse.py $OUT > $OUT/r02_pmc_bench.json && tail -n 30 $OUT/r02_pmc_bench.json
+python3 tools/pmc_bench_parse.py $OUT > $OUT/r03_pmc_bench.json && tail -n 30 $OUT/r03_pmc_bench.json
