@@ -32,7 +32,7 @@ constexpr int EPI_PARTIAL = 100;  // split-K: fp32 partial sums [split][M][n_cti
 // NS = LDS stages: 2 (two workgroups per CU overlap each other's barrier stalls) or 4 (one workgroup per CU with
 // three K-steps of loads in flight: small grids, where every K-step otherwise pays a full memory latency)
 template <int EPI, int BT, int NS = 2>
-__global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(const __bf16* __restrict__ A, int lda,
+__global__ __launch_bounds__(256, (NS * (TILE_BYTES + BT * 128) <= 80 * 1024) ? 2 : 1) void gemm_kernel(const __bf16* __restrict__ A, int lda,
                                                       const __bf16* __restrict__ W, int ldw, int M, int N,
                                                       int ksteps, const float* __restrict__ bias, float alpha,
                                                       void* __restrict__ out, int n_ctile, int nblk, int ct0) {
@@ -106,7 +106,11 @@ __global__ __launch_bounds__(256, NS == 2 ? 2 : 1) void gemm_kernel(const __bf16
             else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LPS) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();  // stage kt landed for every wave; everyone is done reading the buffer refilled next
+        // stage kt landed for every wave; everyone is done reading the buffer refilled next.  A RAW barrier: the fence
+        // inside __syncthreads() is s_waitcnt vmcnt(0), which would drain the stages in flight (NS > 2) at every step
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
         if (kt + NS - 1 < kt1) stage((kt + NS - 1 - kt0) % NS, kt + NS - 1);
         const char* wt = smem + ((kt - kt0) % NS) * STAGE_BYTES;
         const char* at = wt + TILE_BYTES;
@@ -178,9 +182,27 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, __bf16* __restri
 }
 
 // Covers channel tiles [ct0, round_up(N,128)/128) of the output.
+template <int EPI, int BT = 128, int NS = 2>
+int launch_gemm_ns(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
+                   hipStream_t s, int ct0) {
+    const int Kpad = round_up(K, BK);
+    const int n_ctile = round_up(N, BW) / BW - ct0;
+    const int n_ttile = (M + BT - 1) / BT;
+    const int nblk = n_ctile * n_ttile;
+    constexpr int LDS = NS * (TILE_BYTES + BT * 128);
+    static std::atomic<unsigned long long> lds_ready{0};
+    if (!esmk_reserve_lds((const void*)gemm_kernel<EPI, BT, NS>, LDS, lds_ready))
+        ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", LDS);
+    hipLaunchKernelGGL((gemm_kernel<EPI, BT, NS>), dim3(nblk), dim3(256), LDS, s, (const __bf16*)A, lda,
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk, ct0);
+    ESMK_CHECK_LAUNCH("esmk_gemm");
+    return ESMK_OK;
+}
+
 template <int EPI, int BT = 128>
 int launch_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
                 hipStream_t s, int ct0 = 0) {
+    if (esmk_switch("ESMK_GEMM_NS", 2) == 3) return launch_gemm_ns<EPI, BT, 3>(A, lda, W, M, N, K, bias, alpha, out, s, ct0);
     const int Kpad = round_up(K, BK);
     const int n_ctile = round_up(N, BW) / BW - ct0;
     const int n_ttile = (M + BT - 1) / BT;
