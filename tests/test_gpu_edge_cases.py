@@ -285,6 +285,18 @@ def test_esm3_forward_and_logits_do_not_synchronise(esm3):
         torch.cuda.set_sync_debug_mode("default")
     assert torch.equal(got.embeddings, want.embeddings) and torch.equal(got.structure_logits, want.structure_logits)
     assert lg.logits.sequence.shape == (1, L_, 64) and one.sequence_logits.shape == (1, L_, 64)
+    # a batch-1 track next to batch-2 tracks is broadcast (the reference builds its defaults with batch 1, esm3.py:317-341)
+    ss8 = torch.randint(3, 11, (1, L_)).cuda()
+    plddt = torch.rand(1, L_).cuda()
+    a = esm3(sequence_tokens=seq, ss8_tokens=ss8, per_res_plddt=plddt, average_plddt=torch.tensor(0.7).cuda())
+    b = esm3(sequence_tokens=seq, ss8_tokens=ss8.expand(2, L_).contiguous(), per_res_plddt=plddt.expand(2, L_).contiguous(),
+             average_plddt=torch.full((2, L_), 0.7).cuda())
+    assert torch.equal(a.embeddings, b.embeddings) and torch.equal(a.sasa_logits, b.sasa_logits)
+    from oracle import trunk_ref  # checker only
+    ref = trunk_ref.esm3_forward(synth.esm3_weights(128, 2, 8, seed=51), 2, 8, 2, sequence_tokens=seq.cpu(),
+                                 ss8_tokens=ss8.cpu().expand(2, L_), per_res_plddt=plddt.cpu().expand(2, L_),
+                                 average_plddt=torch.full((2, L_), 0.7))
+    close(a.embeddings.cpu(), ref["embeddings"])
 
 
 def test_state_dict_reload_repacks_weights(esmc):
