@@ -164,10 +164,17 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
         issue_unit(1, 1);
         issue_unit(2, 1);
         issue_unit(3, 1);
+#ifdef ESMK_G256_ONEBAR
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // all of tile 0 (block 2 reads U3 without a barrier of its own)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
         asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     }
+#endif
     SEG_BARRIER();
     read_a_kk(smem + 0 * UNIT, 0);
     read_b_kk(smem, 0);
@@ -200,6 +207,32 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
     // Barrier Q(kt): U0-2(kt+1) have landed, and every wave is done with slot U3 of this buffer.
     // Issue order per wave is U0-2(t), U3(t), U0-2(t+1), U3(t+1), ... (6 + 2 pieces), so "all but the two
     // youngest groups" = s_waitcnt vmcnt(8).  M1: tile kt+1 exists, M2: tile kt+2 exists.
+#ifdef ESMK_G256_ONEBAR
+    // Experiment (round 3), NOT the default: ONE workgroup barrier per K-tile instead of two.  Bit-identical; back to
+    // back on resident operands it is 2-5 % faster (FFN up-projection 354 -> 339..346 us, 8192 x 8192 x 1536 +5 %), but INSIDE
+    // the forward, where the activations come from beyond L2, it is slower (FFN up-projection 371.8 -> 377 us in situ,
+    // 40.30 -> 40.45 ms per step): with two buffers one barrier means ONE K-tile of flight instead of 1.5.  All eight pieces of tile kt+2 are issued
+    // behind barrier S(kt) (into the buffer tile kt has just finished with) during block 4, one per MFMA pair: one
+    // K-tile of flight instead of 1.5, half the rendezvous.  S(kt): every piece of tile kt+1 has landed for every wave
+    // (nothing younger is outstanding: vmcnt(0)), and every wave has issued its last read of buffer kt (block 3).
+#define KTILE(M1, M2)                                                                              \
+    {                                                                                              \
+        const char* cur = smem + (kt & 1) * KBUF;                                                  \
+        const char* nxt = smem + ((kt + 1) & 1) * KBUF;                                            \
+        MFMA_BLOCK(0, 0, { read_a_kk(cur + 0 * UNIT, 1); read_b_kk(cur, 1); }, NOP_,               \
+                   { if (M1 && kt > 0) issue_piece(3, 1, kt + 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)   \
+        MFMA_BLOCK(0, 1, { read_a_kk(cur + 3 * UNIT, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_) \
+        MFMA_BLOCK(1, 0, { read_a_kk(cur + 3 * UNIT, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_, NOP_) \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        SEG_BARRIER();                                                                             \
+        MFMA_BLOCK(1, 1, { if (M1) { read_a_kk(nxt + 0 * UNIT, 0); read_b_kk(nxt, 0); } },         \
+                   { if (M2) issue_piece(0, 0, kt + 2); }, { if (M2) issue_piece(0, 1, kt + 2); }, \
+                   { if (M2) issue_piece(1, 0, kt + 2); }, { if (M2) issue_piece(1, 1, kt + 2); }, \
+                   { if (M2) issue_piece(2, 0, kt + 2); }, { if (M2) issue_piece(2, 1, kt + 2); }, \
+                   { if (M2) issue_piece(3, 0, kt + 2); })                                         \
+    }
+#else
 #define KTILE(M1, M2)                                                                              \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * KBUF;                                                  \
@@ -229,6 +262,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
         STAMP(6);                                                                                  \
     }
 
+#endif
     int kt = 0;
     for (; kt < ktiles - 2; ++kt) KTILE(true, true)
     if (ktiles >= 2) {

@@ -142,10 +142,17 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     issue_tile(0);
     if (ktiles > 1) {
         issue_tile(1);
+#ifdef ESMK_G288_ONEBAR
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP + NQ) : "memory");  // ALL of tile 0 (no barrier P certifies its Q region)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#else
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NQ + NP) : "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ) : "memory");
     }
+#endif
     SEG_BARRIER();
     read_a_kk(smem + OFF_UA0, 0);
     read_b_kk(smem, 0);
@@ -174,6 +181,34 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
     // Barrier P(kt): Q(kt) (UA1, UA2) has landed for every wave; all waves are done with the P region of this buffer.
     // Barrier Q(kt): P(kt+1) has landed; all waves are done with UA1 / UA2 of this buffer.
     // Issue order per wave: P(t), Q(t), P(t+1), Q(t+1), ...  =>  "all but the two youngest groups" = vmcnt(NP + NQ).
+#ifdef ESMK_G288_ONEBAR
+    // Experiment, NOT the default: ONE workgroup barrier per K-tile as in gemm256.hip.  Bit-identical but slower on this
+    // kernel's six-block K-tiles (FFN down-projection 170 -> 187 us, QKV -1 %): the 1.5 K-tiles of flight matter more here.
+    // every piece of tile kt+2 is issued behind barrier
+    // S(kt), into the buffer tile kt is done with - P pieces 0-4 in the last block of tile kt, the rest in the first
+    // block of tile kt+1.  S(kt): all of tile kt+1 has landed for every wave (nothing younger outstanding: vmcnt(0)),
+    // and every wave has issued its last read of buffer kt.
+#define KTILE(M1, M2)                                                                              \
+    {                                                                                              \
+        const char* cur = smem + (kt & 1) * KBUF;                                                  \
+        const char* nxt = smem + ((kt + 1) & 1) * KBUF;                                            \
+        MFMA_BLOCK(0, 0, { read_a_kk(cur + OFF_UA0, 1); read_b_kk(cur, 1); },                      \
+                   { if (M1 && kt > 0 && HI) issue_P(5, kt + 1); }, { if (M1 && kt > 0 && NQ > 0) issue_Q(0, kt + 1); }, \
+                   { if (M1 && kt > 0 && NQ > 1) issue_Q(1, kt + 1); }, { if (M1 && kt > 0 && NQ > 2) issue_Q(2, kt + 1); }, NOP_) \
+        MFMA_BLOCK(0, 1, { read_a_kk(cur + OFF_UA1, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        MFMA_BLOCK(1, 0, { read_a_kk(cur + OFF_UA1, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)           \
+        if constexpr (NQM == 3) {                                                                  \
+            MFMA_BLOCK(1, 1, { read_a_kk(cur + OFF_UA2, 0); }, NOP_, NOP_, NOP_, NOP_, NOP_)       \
+            MFMA_BLOCK(2, 0, { read_a_kk(cur + OFF_UA2, 1); }, NOP_, NOP_, NOP_, NOP_, NOP_)       \
+        }                                                                                          \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                           \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                         \
+        SEG_BARRIER();                                                                             \
+        MFMA_BLOCK(NQM - 1, 1, { if (M1) { read_a_kk(nxt + OFF_UA0, 0); read_b_kk(nxt, 0); } },    \
+                   { if (M2) issue_P(0, kt + 2); }, { if (M2) issue_P(1, kt + 2); }, { if (M2) issue_P(2, kt + 2); }, \
+                   { if (M2) issue_P(3, kt + 2); }, { if (M2) issue_P(4, kt + 2); })               \
+    }
+#else
 #define KTILE(M1, M2)                                                                              \
     {                                                                                              \
         const char* cur = smem + (kt & 1) * KBUF;                                                  \
@@ -200,6 +235,7 @@ __device__ __forceinline__ void gemm288_body(const __bf16* __restrict__ A, int l
                    { if (M2 && NQ > 2) issue_Q(2, kt + 2); }, NOP_, NOP_)                          \
     }
 
+#endif
     int kt = 0;
     for (; kt < ktiles - 2; ++kt) KTILE(true, true)
     if (ktiles >= 2) {
