@@ -286,6 +286,8 @@ int esmk_gemm288(const void* A, int lda, const void* W, int M, int N, int K, flo
 int esmk_gemm192(const void* A, int lda, const void* W, int M, int N, int K, float alpha, void* out, hipStream_t s);
 int esmk_gemm288_stats(const void* A, int lda, const void* W, int M, int d, int K, void* out, float* stats, int tc,
                        hipStream_t s);
+int esmk_gemm256_stats(const void* A, int lda, const void* W, int M, int d, void* out, float* stats, hipStream_t s,
+                       int n_ctile);
 
 #ifdef ESMK_EXPERIMENTS
 // Alternative kernels of the experiments build only (libesmk_x.so): the four-wave 128x128-wave-tile kernels
@@ -382,23 +384,61 @@ extern "C" int esmk_gemm_noalloc(const void* A, int lda, const void* W, int M, i
     return esmk_gemm_ws(A, lda, W, M, N, K, epilogue, bias, alpha, out, part, need, stream);
 }
 
-// Channel-tile width the dispatch below picks for the QKV projection (N = 3 d, K = d, bf16, no bias) when that kernel
-// can also emit the q-side LayerNorm partial sums (tiles must not straddle the q / k boundary); 0 otherwise.
-static int qkv_stats_tile(int M, int d) {
-    if (esmk_switch("ESMK_GEMM_TILE", 0) != 0 || !esmk_switch("ESMK_GEMM_288", 1) || esmk_switch("ESMK_GEMM_192", 0)) return 0;
-    const long long N = 3LL * d, nt = (M + 255) / 256;
-    if ((N % 288) == 0 && (N % 256) != 0 && nt * (N / 288) >= 128) return (d % 288) == 0 ? 288 : 0;
-    if ((N % 192) == 0) {
-        const long long c192 = (nt * (N / 192) + 255) / 256 * 192, c256 = (nt * ((N + 255) / 256) + 255) / 256 * 256;
-        if (nt * (N / 192) >= 128 && c192 < c256) return (d % 192) == 0 ? 192 : 0;
+// Channel-tile width for a LARGE bf16-output problem without bias: 288, 192 or 256; 0 = not large (the 128-tile kernels
+// and split-K below take it).  Cost model: workgroups run one per CU, so a launch takes ceil(tiles / 256) rounds of a
+// duration proportional to the tile width; measured on 19 shapes with N % 576 == 0 (tools/gemm_tile_pick.py,
+// profiles/r03_gemm_tile_pick.txt) the model orders the three widths correctly wherever they differ by more than 3 %
+// up to 4 rounds; beyond that the rounds blur and the widest tile without a ragged column (288) stays best.
+//   N % 288 == 0 (and not % 256): 288, unless at <= 4 rounds a narrower width needs less (8192 x 1152: 192-wide is one
+//     full round, 288-wide one half-empty one: 32.0 -> 25.3 us; 4096 x 3456: 256-wide 34.6 -> 32.8 us)
+//   else N % 192 == 0 and 192-wide needs less than 256-wide (d_model 1536 at 8192 tokens): 192
+//   else 256 when there are at least 128 tiles.
+static int wide_tile_pick(int M, int N) {
+    if (!esmk_switch("ESMK_GEMM_288", 1)) return 0;
+    const long long nt = (M + 255) / 256, nc256 = (N + 255) / 256;
+    auto rounds = [&](long long cols) { return (nt * cols + 255) / 256; };
+    const bool big = nt * nc256 >= 128;
+    const bool ok288 = (N % 288) == 0 && (N % 256) != 0 && nt * (N / 288) >= 128;
+    const bool ok192 = (N % 192) == 0 && nt * (N / 192) >= 128;
+    const long long c256 = rounds(nc256) * 256, c192 = ok192 ? rounds(N / 192) * 192 : 0;
+    if (esmk_switch("ESMK_GEMM_192", 0) && ok192) return 192;
+    if (ok288) {
+        const long long r288 = rounds(N / 288);
+        long long best = r288 * 288;
+        int pick = 288;
+        if (r288 <= 4 && esmk_switch("ESMK_GEMM_PICK", 1)) {
+            if (big && c256 < best) best = c256, pick = 256;   // on a tie with 192-wide tiles the wider ones are not slower
+            if (ok192 && c192 < best) best = c192, pick = 192;
+        }
+        return pick;
     }
+    if (ok192 && c192 < c256) return 192;
+    return big ? 256 : 0;
+}
+
+// Channel-tile width of the kernel that computes the QKV projection (N = 3 d, K = d, bf16, no bias) AND emits the q-side
+// LayerNorm partial sums; 0 when no such kernel takes the shape.  288 / 192: when esmk_gemm's dispatch picks that width
+// and its tiles do not straddle the q / k boundary (one part per wave half-tile).  256: the 256-tile kernel with 64- or
+// 128-channel parts, where the dispatch picks 256-wide tiles, or 192-wide ones that would straddle (d_model 2560).
+// Where it picks 288-wide tiles that straddle (d_model 960 at >= 12288 tokens) the three-call path stays: measured,
+// the narrower tiles cost more than the fused q side saves (tools/qfuse_ab.py: 279.8 vs 284.4 us at 64 x 512).
+static int qkv_stats_tile(int M, int d) {
+    if (esmk_switch("ESMK_GEMM_TILE", 0) != 0) return 0;
+    const int pick = wide_tile_pick(M, 3 * d);
+    if (pick == 288) return (d % 288) == 0 ? 288 : 0;
+    if (pick == 192 && (d % 192) == 0) return 192;
+    const int stats256 = esmk_switch("ESMK_QKV_STATS256", 1);
+    if (pick && stats256 != 0 && (d % 64) == 0 && (d <= 2048 || ((d % 128) == 0 && d <= 4096)) &&
+        (long long)((M + 255) / 256) * ((3 * d + 255) / 256) >= 128)
+        return 256;
     return 0;
 }
 
+static int qkv_stats_parts_of(int tc, int d) { return tc == 256 ? (d > 2048 ? d / 128 : d / 64) : tc ? 2 * (d / tc) : 0; }
+
 extern "C" int esmk_qkv_stats_parts(int M, int d_model) {
     if (M <= 0 || d_model <= 0) return 0;
-    const int tc = qkv_stats_tile(M, d_model);
-    return tc ? 2 * (d_model / tc) : 0;
+    return qkv_stats_parts_of(qkv_stats_tile(M, d_model), d_model);
 }
 
 extern "C" int esmk_gemm_qkv_stats(const void* A, int lda, const void* W, int M, int d_model, void* out, float* qstats,
@@ -412,7 +452,15 @@ extern "C" int esmk_gemm_qkv_stats(const void* A, int lda, const void* W, int M,
     if (!tc)
         ESMK_FAIL(ESMK_ERR_UNSUPPORTED, "esmk_gemm_qkv_stats: shape M=%d d=%d has no statistics-emitting kernel "
                   "(esmk_qkv_stats_parts() == 0): use esmk_gemm + esmk_qk_prep", M, d_model);
-    return esmk_gemm288_stats(A, lda, W, M, d_model, d_model, out, qstats, tc, (hipStream_t)stream);
+    if (tc != 256) return esmk_gemm288_stats(A, lda, W, M, d_model, d_model, out, qstats, tc, (hipStream_t)stream);
+    // 256-wide tiles, with esmk_gemm's split dispatch: a last column that is at most half full goes to the 128-tile
+    // kernel when that saves a round of workgroups (it holds v columns only: (nc - 1) * 256 >= 3 d - 128 >= 2 d)
+    const int N = 3 * d_model, nt = (M + 255) / 256, nc = (N + 255) / 256, rem = N - (nc - 1) * 256;
+    const bool split = esmk_switch("ESMK_GEMM_SPLIT", 1) && nc >= 2 && rem <= 128 && (nc - 1) * 256 >= 2 * d_model &&
+                       (nt * (nc - 1) + 255) / 256 < (nt * nc + 255) / 256;
+    const int rc = esmk_gemm256_stats(A, lda, W, M, d_model, out, qstats, (hipStream_t)stream, split ? nc - 1 : nc);
+    if (rc != ESMK_OK || !split) return rc;
+    return launch_gemm<ESMK_EPI_BF16, 64>(A, lda, W, M, N, d_model, nullptr, 1.f, out, (hipStream_t)stream, (nc - 1) * 2);
 }
 
 extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N, int K, int epilogue, const float* bias,
@@ -437,23 +485,14 @@ extern "C" int esmk_gemm_ws(const void* A, int lda, const void* W, int M, int N,
         // reduce only (the 256-tile kernel has biased instantiations of its other epilogues)
         const bool bias128 = bias && epilogue == ESMK_EPI_BF16;
         const bool big = !bias128 && (long long)((M + 255) / 256) * ((N + 255) / 256) >= 128;
-        // widths that are multiples of 288 but not of 256 (d_model 1152): 288-channel tiles, no half-empty column
-        const int use288 = esmk_switch("ESMK_GEMM_288", 1);
-        const int force192 = esmk_switch("ESMK_GEMM_192", 0);  // prefer 192-channel tiles wherever N % 192 == 0
-        if (force192 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 192) == 0 && (long long)((M + 255) / 256) * (N / 192) >= 128)
-            return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
-        if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 288) == 0 && (N % 256) != 0 &&
-            (long long)((M + 255) / 256) * (N / 288) >= 128)
-            return esmk_gemm288(A, lda, W, M, N, K, alpha, out, s);
-        // 192-channel tiles when they need fewer tile-width-weighted rounds of workgroups than 256-wide ones
-        // (d_model 1536 at 8192 tokens: N = 1536 is 256 workgroups of 192 channels = one full round, but 192
-        // workgroups of 256 = one round at 75 %; N = 4608: 3 rounds either way, of narrower tiles)
-        if (use288 && ov == 0 && !bias && epilogue == ESMK_EPI_BF16 && (N % 192) == 0) {
-            const long long nt = (M + 255) / 256;
-            const long long c192 = (nt * (N / 192) + 255) / 256 * 192, c256 = (nt * ((N + 255) / 256) + 255) / 256 * 256;
-            if (nt * (N / 192) >= 128 && c192 < c256) return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
+        // bf16 output without bias: 288- / 192- / 256-wide tiles by the round model of wide_tile_pick()
+        int pick = 0;
+        if (ov == 0 && !bias && epilogue == ESMK_EPI_BF16) {
+            pick = wide_tile_pick(M, N);
+            if (pick == 288) return esmk_gemm288(A, lda, W, M, N, K, alpha, out, s);
+            if (pick == 192) return esmk_gemm192(A, lda, W, M, N, K, alpha, out, s);
         }
-        if ((ov == 256 && !bias128) || (ov == 0 && big)) {
+        if ((ov == 256 && !bias128) || (ov == 0 && (big || pick == 256))) {
             const int persist = esmk_switch("ESMK_GEMM_PERSIST", 0);
 #ifdef ESMK_EXPERIMENTS
             if (persist && (epilogue == ESMK_EPI_BF16 || epilogue == ESMK_EPI_SWIGLU)) {

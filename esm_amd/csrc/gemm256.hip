@@ -52,13 +52,20 @@ __device__ unsigned long long g_stamps[8 * 64];
 
 constexpr int EPI_SWIGLU_BIAS = 102;  // internal: ESMK_EPI_SWIGLU with ffn.1.bias; its own instantiation, so the
                                       // bias-free kernel of the ESM C / ESM3 trunks is unchanged
+constexpr int EPI_BF16_STATS = 103;   // internal: ESMK_EPI_BF16 of the QKV projection that also emits the q-side QK-LayerNorm
+                                      // partial sums (gemm288.hip has the same for its tile widths): every wave sums its fp32
+                                      // outputs per token over each 64-channel block (128-channel block when d_model > 2048,
+                                      // so that a token has at most 32 parts) while they pass through the epilogue, and blocks
+                                      // below stat_cols (= d_model: the q columns) store stats[token][block] = (sum, sum of squares)
 template <int EPI_>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restrict__ A, int lda,
                                                          const __bf16* __restrict__ W, int ldw, int M, int N,
                                                          int ktiles, const float* __restrict__ bias, float alpha,
-                                                         void* __restrict__ out, int n_ctile, int nblk, int gt) {
+                                                         void* __restrict__ out, int n_ctile, int nblk, int gt,
+                                                         float* __restrict__ stats, int stat_cols) {
     constexpr bool kSwigluBias = (EPI_ == EPI_SWIGLU_BIAS);
-    constexpr int EPI = kSwigluBias ? ESMK_EPI_SWIGLU : EPI_;
+    constexpr bool kStats = (EPI_ == EPI_BF16_STATS);
+    constexpr int EPI = kSwigluBias ? ESMK_EPI_SWIGLU : kStats ? ESMK_EPI_BF16 : EPI_;
 #ifdef ESMK_GEMM_DBG
     constexpr int dbg = ESMK_GEMM_DBG;  // diagnostic builds only: 1 = no DMA, 2 = no LDS reads, 4 = no epilogue
 #else
@@ -291,6 +298,15 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
         constexpr int CW = (EPI == ESMK_EPI_SWIGLU) ? 64 : 128;     // channels per wave after the epilogue op
         constexpr int PITCH = CW * 2 + 16;                          // row pitch in bytes (+16: bank spread)
         char* stg = smem + wave * (64 * PITCH);
+        float ssum[kStats ? 2 : 1][2][2], ssq[kStats ? 2 : 1][2][2];  // kStats: by (qm, qn, ni), this lane's four channel quads
+        if constexpr (kStats) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) ssum[a][b][c] = ssq[a][b][c] = 0.f;
+        }
 #pragma unroll
         for (int qm = 0; qm < 2; ++qm)
 #pragma unroll
@@ -326,6 +342,14 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
                             } else {
                                 v = scale4(v, alpha);
                             }
+                            if constexpr (kStats) {  // summed while the values pass through (a sweep of its own over the
+                                                     // accumulators doubles their live range)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    ssum[qm][qn][ni] += v[r];
+                                    ssq[qm][qn][ni] += v[r] * v[r];
+                                }
+                            }
                             u32x2 pk;
                             pk.x = pack_bf16x2(v[0], v[1]);
                             pk.y = pack_bf16x2(v[2], v[3]);
@@ -333,6 +357,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
                         }
                     }
                 }
+        if constexpr (kStats) {
+            const bool g128 = stat_cols > 2048;                 // 128-channel parts: the two qm blocks of the wave together
+            const int parts = stat_cols >> (g128 ? 7 : 6);
+            const int cbw = c0 + wm * 128;                      // first channel of this wave (wave-uniform)
+#pragma unroll
+            for (int qm = 0; qm < 2; ++qm) {
+                if (g128 && qm) break;
+                const int cb = cbw + qm * 64;
+                if (cb >= stat_cols) break;                     // k and v columns: no statistics
+#pragma unroll
+                for (int qn = 0; qn < 2; ++qn)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) {
+                        // the four 16-lane groups hold four different channel quads of the same 16 tokens
+                        float sm = ssum[qm][qn][ni], sq = ssq[qm][qn][ni];
+                        if (g128) {
+                            sm += ssum[1][qn][ni];
+                            sq += ssq[1][qn][ni];
+                        }
+                        sm += __shfl_xor(sm, 16);
+                        sq += __shfl_xor(sq, 16);
+                        sm += __shfl_xor(sm, 32);
+                        sq += __shfl_xor(sq, 32);
+                        const int t = t0 + wn * 64 + qn * 32 + ni * 16 + (lane & 15);
+                        if (lane < 16 && t < M) {
+                            float* sp = stats + ((size_t)t * parts + (g128 ? cb >> 7 : cb >> 6)) * 2;
+                            sp[0] = sm;
+                            sp[1] = sq;
+                        }
+                    }
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         constexpr int LPR = CW / 8;         // lanes per row (16 B each)
         constexpr int RPI = 64 / LPR;       // rows per wave-instruction
@@ -372,7 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const __bf16* __restric
 
 template <int EPI>
 int launch(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, float alpha, void* out,
-           hipStream_t s, int n_ctile) {
+           hipStream_t s, int n_ctile, float* stats = nullptr, int stat_cols = 0) {
     const int Kpad = round_up(K, BK);
     const int n_ttile = (M + TB - 1) / TB;
     const int nblk = n_ctile * n_ttile;
@@ -382,7 +438,7 @@ int launch(const void* A, int lda, const void* W, int M, int N, int K, const flo
     if (!esmk_reserve_lds((const void*)gemm256_kernel<EPI>, LDS_BYTES, lds_ready))
         ESMK_FAIL(ESMK_ERR_LAUNCH, "esmk_gemm: cannot reserve %d bytes of LDS", (int)(LDS_BYTES));
     hipLaunchKernelGGL(gemm256_kernel<EPI>, dim3(nblk), dim3(512), LDS_BYTES, s, (const __bf16*)A, lda,
-                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk, gt);
+                       (const __bf16*)W, Kpad, M, N, Kpad / BK, bias, alpha, out, n_ctile, nblk, gt, stats, stat_cols);
     ESMK_CHECK_LAUNCH("esmk_gemm(256)");
     return ESMK_OK;
 }
@@ -403,6 +459,13 @@ int esmk_gemm256(const void* A, int lda, const void* W, int M, int N, int K, int
         case ESMK_EPI_BIAS_GELU: return launch<ESMK_EPI_BIAS_GELU>(A, lda, W, M, N, K, bias, alpha, out, s, n_ctile);
         default: ESMK_FAIL(ESMK_ERR_INVALID_ARG, "esmk_gemm: unknown epilogue %d", epilogue);
     }
+}
+
+// QKV projection (N = 3 d, bf16 out, no bias) that also emits the q-side LayerNorm partial sums (EPI_BF16_STATS above):
+// stats is [M][parts][2] with parts = d / 64 (d <= 2048) or d / 128.  The caller (gemm.hip) checks the shape.
+int esmk_gemm256_stats(const void* A, int lda, const void* W, int M, int d, void* out, float* stats, hipStream_t s,
+                       int n_ctile) {
+    return launch<EPI_BF16_STATS>(A, lda, W, M, 3 * d, d, nullptr, 1.f, out, s, n_ctile, stats, d);
 }
 
 #ifdef ESMK_STAMPS

@@ -41,8 +41,12 @@ def _reference(qkv, cu, H, gq, gk, bq, bk, positions):
     return out.reshape(N, d)
 
 
-@pytest.mark.parametrize("lens,H,biased", [([512] * 5 + [300, 129, 64, 1], 18, False), ([700, 1300, 64, 1, 800], 18, True),
-                                           ([512] * 15 + [400, 112], 24, False)])
+@pytest.mark.parametrize("lens,H,biased", [([512] * 9 + [300, 129, 64, 1], 18, False), ([700, 1300, 64, 1, 800], 18, True),
+                                           ([512] * 15 + [400, 112], 24, False),
+                                           # d 960 / 2560: the 256-tile kernel's statistics epilogue (64- / 128-channel parts;
+                                           # d 960: the q / k boundary lies inside a tile, and the last tile column splits off)
+                                           ([512] * 8 + [300, 129, 1], 15, False), ([700, 1300, 64, 1, 800, 900], 15, True),
+                                           ([512] * 3 + [300, 129, 1], 40, False)])
 def test_qfused_against_reference_and_three_call_path(lens, H, biased):
     from esm_amd import _lib as L
     from esm_amd import engine
@@ -52,7 +56,9 @@ def test_qfused_against_reference_and_three_call_path(lens, H, biased):
     pb = pack_lengths(lens)
     M = pb.n_tokens
     parts = lib.esmk_qkv_stats_parts(M, d)
-    assert parts == (8 if H == 18 else 16), parts
+    # d 960: 4526 tokens take 256-wide tiles (64-channel parts), 3765 tokens 192-wide ones (one part per wave half-tile)
+    # d 1152: 5102 tokens take 288-wide tiles, 2865 tokens 192-wide ones (12 parts)
+    assert parts == {18: 8 if M > 4352 else 12, 24: 16, 15: 15 if M > 4352 else 10, 40: 20}[H], parts
     g = torch.Generator().manual_seed(M + H)
     xn = torch.randn(M, d, generator=g).bfloat16()
     W = torch.randn(3 * d, d, generator=g) * 0.04 + 0.004   # non-zero row means: q and k are not centred
@@ -87,7 +93,8 @@ def test_qfused_against_reference_and_three_call_path(lens, H, biased):
     stats = torch.full((M, parts, 2), float("nan"), dtype=torch.float32, device="cuda")
     L.check(lib.esmk_gemm_qkv_stats(xd.data_ptr(), d, Wp.data_ptr(), M, d, qkv_b.data_ptr(), stats.data_ptr(), _s()))
     torch.cuda.synchronize()
-    assert torch.equal(qkv_b, raw)                      # the projection itself is the same kernel arithmetic
+    # the projection itself is the same arithmetic (every tile kernel adds the same MFMA products in the same K order)
+    assert torch.equal(qkv_b, raw)
     qr = qkv_ref[:, :d].reshape(M, parts, d // parts)
     want = torch.stack([qr.sum(-1), (qr * qr).sum(-1)], -1)
     got = stats.cpu()
@@ -148,8 +155,12 @@ def test_qfused_rejects_bad_arguments():
     lib = L.lib()
     assert lib.esmk_qkv_stats_parts(1024, 1152) == 0      # too few tiles: the 128-tile kernel runs
     assert lib.esmk_qkv_stats_parts(2048, 1152) == 12     # 192-channel tiles
-    assert lib.esmk_qkv_stats_parts(32768, 2560) == 0     # 256-channel tiles: no statistics
-    assert lib.esmk_qkv_stats_parts(32768, 960) == 0      # 288-channel tiles straddle the q / k boundary
+    assert lib.esmk_qkv_stats_parts(32768, 2560) == 20    # 256-channel tiles, 128-channel parts
+    assert lib.esmk_qkv_stats_parts(32768, 960) == 0      # 288-channel tiles straddle the q / k boundary (and beat narrower ones)
+    assert lib.esmk_qkv_stats_parts(4526, 960) == 15      # 256-channel tiles, 64-channel parts
+    assert lib.esmk_qkv_stats_parts(8192, 960) == 10      # 192-channel tiles
+    assert lib.esmk_qkv_stats_parts(2048, 960) == 0       # too few tiles
+    assert lib.esmk_qkv_stats_parts(32768, 1000) == 0     # d % 64
     assert lib.esmk_qkv_stats_parts(32768, 1152) == 8
     x = torch.zeros(8, device="cuda")
     rc = lib.esmk_gemm_qkv_stats(x.data_ptr(), 1152, x.data_ptr(), 1024, 1152, x.data_ptr(), x.data_ptr(), _s())
@@ -162,17 +173,21 @@ def test_qfused_rejects_bad_arguments():
     assert rc == -1   # parts must divide d
 
 
-def test_trunk_fused_and_unfused_paths_agree_on_a_padded_batch():
-    """ESM C 600M-shaped blocks (d 1152): the default forward of a padded 8 x 512 batch packs all 4096 positions (fused
-    path, pad_tail layout); drop_pads=True packs the 805 valid ones on the host (three-call path: too few tiles)."""
+@pytest.mark.parametrize("d,H,L_,lens,parts", [
+    (1152, 18, 512, [512, 30, 20, 100, 1, 64, 50, 28], 18),          # 4096 positions: 256-wide tiles, 64-channel parts
+    (1152, 18, 512, [512, 30, 20, 100, 1, 64, 50, 28, 7, 30] + [20] * 10, 8),  # 10240 positions: 288-wide tiles
+    (960, 15, 512, [512, 30, 20, 100, 1, 64, 50, 28] * 2, 10),       # ESM C 300M width, 8192 positions: 192-wide tiles
+    (2560, 40, 256, [256, 30, 20, 100, 1, 64, 50, 28], 20)])         # ESM C 6B width: 256-wide tiles, 128-channel parts
+def test_trunk_fused_and_unfused_paths_agree_on_a_padded_batch(d, H, L_, lens, parts):
+    """Two blocks of every ESM C width: the default forward of a padded batch packs all B x L positions (fused path,
+    pad_tail layout); drop_pads=True packs only the valid ones on the host (three-call path: too few tiles)."""
     from esm_amd import _lib as L
     from esm_amd.esmc import ESMC
-    m = ESMC(1152, 18, 2)
-    m.load_state_dict(synth.esmc_weights(1152, 2, seed=3))
+    m = ESMC(d, H, 2)
+    m.load_state_dict(synth.esmc_weights(d, 2, seed=3))
     m = m.cuda()
-    lens = [512, 30, 20, 100, 1, 64, 50, 28]
-    assert L.lib().esmk_qkv_stats_parts(8 * 512, 1152) == 8 and L.lib().esmk_qkv_stats_parts(sum(lens), 1152) == 0
-    tok = synth.synth_tokens(lens, pad_to=512, seed=5).cuda()
+    assert L.lib().esmk_qkv_stats_parts(len(lens) * L_, d) == parts and L.lib().esmk_qkv_stats_parts(sum(lens), d) == 0
+    tok = synth.synth_tokens(lens, pad_to=L_, seed=5).cuda()
     fused = m(tok)
     plain = m(tok, drop_pads=True)
     torch.cuda.synchronize()

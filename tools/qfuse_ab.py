@@ -17,7 +17,9 @@ rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 st = torch.cuda.current_stream().cuda_stream
 q_scale = 0.125 * math.log2(math.e)
 for name, lens, H in (("c2 64x512 d1152", [512] * 64, 18), ("c3 16x512 d1536", [512] * 16, 24),
-                      ("c4 varlen d1152", list(np.random.default_rng(0).integers(64, 2048, 31)), 18)):
+                      ("c4 varlen d1152", list(np.random.default_rng(0).integers(64, 2048, 31)), 18),
+                      ("300M 64x512 d960", [512] * 64, 15), ("300M 16x512 d960", [512] * 16, 15),
+                      ("6B 32x512 d2560", [512] * 32, 40), ("c5 4x4096 d2560", [4096] * 4, 40)):
     d = 64 * H
     pb = pack_lengths(lens)
     M = pb.n_tokens
