@@ -358,10 +358,15 @@ def test_gemm_split_k_not_for_big_shapes():
     assert lib.esmk_gemm_workspace_bytes(512, 1536, 256) == 0    # too few K-steps to split
 
 
-@pytest.mark.parametrize("M,N,K", [(8192, 1152, 64), (8200, 1152, 128), (9000, 3456, 192), (20000, 1152, 3072),
-                                   (32768, 3456, 1152)])
+@pytest.mark.parametrize("M,N,K", [(16300, 1152, 64), (16384, 1152, 128), (16000, 3456, 192), (16384, 1152, 3072),
+                                   (32768, 3456, 1152),
+                                   # same widths at sizes where the round-cost pick takes 192- or 256-wide tiles instead
+                                   (8192, 1152, 64), (8200, 1152, 128), (9000, 3456, 192), (20000, 1152, 3072),
+                                   (8192, 1152, 1152), (4096, 3456, 1152), (8192, 2880, 960), (12288, 3456, 1152)])
 def test_gemm_288_channel_tiles(M, N, K):
-    """Widths that are multiples of 288 but not 256 take the 288x256 kernel (1, 2, 3, 48, 18 K-tiles; ragged M)."""
+    """Widths that are multiples of 288 but not 256: the 288x256 kernel where it needs no more rounds x width than
+    narrower tiles (first five: 1, 2, 3, 48, 18 K-tiles; ragged M), else the 192- or 256-wide kernels
+    (wide_tile_pick() in gemm.hip)."""
     L, lib, engine = _env()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).bfloat16().cuda()
