@@ -213,8 +213,11 @@ int esmk_attn_varlen(const void* qkv_bf16, void* ctx_bf16, const int32_t* cu_seq
  * esmk_attn_varlen up to bf16 rounding, as three calls:
  *   1. esmk_gemm_qkv_stats: qkv = A . W_qkv^T (bf16 [M, 3d], what esmk_gemm(EPI_BF16) writes) and, from the fp32
  *      accumulators of the q columns, qstats f32 [M][parts][2] = (sum, sum of squares) over d/parts columns each.
- *      parts = esmk_qkv_stats_parts(M, d): 0 when the GEMM kernel that this shape dispatches to has tiles straddling
- *      the q / k boundary or emits no statistics (then use the three separate calls).
+ *      parts = esmk_qkv_stats_parts(M, d) <= 32: one part per wave half-tile of the 288- / 192-channel-tile kernels, or
+ *      per 64 (d <= 2048) / 128 channels of the 256-tile kernel (any d % 64 == 0, the q / k boundary may lie inside a
+ *      tile).  0 = no statistics-emitting kernel takes the shape (small M; d % 64 != 0; d 960 from about 12 k tokens,
+ *      where 288-wide tiles that straddle the boundary win the projection): then use the three separate calls.
+ *      The qkv it writes is bit-identical to esmk_gemm's.
  *   2. esmk_k_prep: k_ln (gamma_k, beta_k or NULL) + rotary on the k columns only, in place; and, when qstats is given,
  *      the partials reduced to q_mean_rstd f32 [M][2] = (mean, 1/sqrt(var + eps)) of every token's q row (qstats NULL:
  *      k only).  qstats / q_mean_rstd 8-byte aligned.
