@@ -30,6 +30,9 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int SM_MAX_PARTS = 64;  // partial sums per row the prologue accepts (d_model <= 4096)
+constexpr long long SM_TWO_STAGE_TILES = 280;  // 128 x 128 tiles from which the two-stage, two-workgroups-per-CU variant runs
+                                               // (tools/sm_gemm_bench.py with ESMK_SM_TILE = 64 / 128 / 2, cold operands,
+                                               // profiles/r03_sm_gemm_variants.txt: behind at 256 tiles, 5-15 % ahead from 288)
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
@@ -389,12 +392,17 @@ extern "C" int esmk_gemm_lnfold(const void* xb, int lda, const float* stats, int
     a.A = (const __bf16*)xb; a.lda = lda; a.W = (const __bf16*)W_folded; a.ldw = d; a.M = M; a.N = N; a.ksteps = d / BK;
     a.stats = stats; a.parts = parts; a.u = u; a.v = v; a.eps = eps; a.d = d; a.out = out;
     hipStream_t s = (hipStream_t)stream;
-    // tile: 128 x 128 tokens (half the staged bytes per FLOP) once that still gives every CU a workgroup, else 128 x 64
-    const int sw = esmk_switch("ESMK_SM_TILE", 0);
-    const bool wide = sw ? sw == 128 : (long long)((M + 127) / 128) * ((N + 127) / 128) >= 224;
-#define LNFOLD_CASE(EPI)                                                                            \
-    return wide ? launch_sm<ROLE_LN, EPI, 128, 128, 3>(a, s, "esmk_gemm_lnfold")                   \
-                : launch_sm<ROLE_LN, EPI, 128, 64, 3>(a, s, "esmk_gemm_lnfold")
+    // tile: 128 x 64 tokens, three stages (two workgroups per CU) while that is what it takes to give every CU work;
+    // 128 x 128, three stages, one workgroup per CU (half the staged bytes per FLOP) from 224 tiles; 128 x 128 with TWO
+    // stages, two workgroups per CU, once there are about two such tiles per CU (mid-sized batches: the partner workgroup
+    // covers a stage's round trip better than a third stage does)
+    const int sw = esmk_switch("ESMK_SM_TILE", 0);  // experiments: 64 / 128 / 2 force a variant
+    const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    const int variant = sw ? sw : tiles128 >= SM_TWO_STAGE_TILES ? 2 : tiles128 >= 224 ? 128 : 64;
+#define LNFOLD_CASE(EPI)                                                                                       \
+    return variant == 2     ? launch_sm<ROLE_LN, EPI, 128, 128, 2>(a, s, "esmk_gemm_lnfold")                   \
+           : variant == 128 ? launch_sm<ROLE_LN, EPI, 128, 128, 3>(a, s, "esmk_gemm_lnfold")                   \
+                            : launch_sm<ROLE_LN, EPI, 128, 64, 3>(a, s, "esmk_gemm_lnfold")
     switch (epilogue) {
         case ESMK_EPI_BF16: LNFOLD_CASE(ESMK_EPI_BF16);
         case ESMK_EPI_F32: LNFOLD_CASE(ESMK_EPI_F32);

@@ -30,6 +30,8 @@ def _fold(lib, W, gam, bet, mode):
     (512, 1536, 8192, "swiglu", 0.2),   # 256 tiles of 128 x 128: the wide-tile instantiation
     (130, 960, 5120, "swiglu", 0.0), (300, 128, 360, "f32", 0.1),
     (256, 1152, 3456, "bf16", 25.0),    # |mean| = 12 sigma: the mean's share of the accumulator must cancel
+    (1000, 1536, 4608, "bf16", 0.1), (1024, 960, 5120, "swiglu", -0.2),   # >= 280 tiles: two stages, two workgroups per CU
+    (900, 1152, 3840, "f32", 0.0),
 ])
 def test_lnfold_projection_vs_torch(M, d, N, epi, offset):
     lib = L.lib()

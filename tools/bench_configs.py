@@ -48,6 +48,8 @@ def esmc(d, H, NL):
     m = ESMC(d, H, NL)
     m.load_state_dict(dev_weights(synth.esmc_shapes(d, NL)))
     m = m.cuda()
+    if os.environ.get("ESMK_SMALL_TOKENS"):   # experiments: move the small-batch path's token limit (product: 1024)
+        m.transformer.small_tokens = int(os.environ["ESMK_SMALL_TOKENS"])
     m._engines()
     return m
 
@@ -68,6 +70,8 @@ def c3(B=16, L=512):
     m = ESM3(d, H, VH, NL)
     m.load_state_dict(dev_weights(synth.esm3_shapes(d, NL, VH)))
     m = m.cuda()
+    if os.environ.get("ESMK_SMALL_TOKENS"):
+        m.transformer.small_tokens = int(os.environ["ESMK_SMALL_TOKENS"])
     seq = synth.synth_tokens([L] * B).cuda()
     g = torch.Generator().manual_seed(1)
     struct = torch.randint(0, 4096, (B, L), generator=g).cuda()
