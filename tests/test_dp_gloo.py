@@ -21,7 +21,7 @@ def fake_compute(tokens, lengths):
 
 def make_sequences():
     g = torch.Generator().manual_seed(11)
-    lens = [5, 64, 17, 33, 2, 48, 9, 21, 40, 7, 3]
+    lens = [5, 64, 17, 33, 2, 48, 9, 21, 40, 7, 3, 60, 50, 30, 64, 12]   # best-fit packs of <= 64 tokens: 8 packs, 4 rounds on 2 ranks
     return [torch.randint(4, 24, (n,), generator=g) for n in lens]
 
 
